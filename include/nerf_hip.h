@@ -1,0 +1,132 @@
+/*
+ * nerf_hip.h -- C ABI of libnerf_hip.so, the MI355X (gfx950) implementation of the
+ * ray-march -> encode -> MLP -> composite path of josedelrey/nerf-pytorch.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless said otherwise;
+ *     inputs are borrowed, outputs are caller-allocated; the library allocates nothing
+ *     and keeps no pointer after a call returns;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only
+ *     enqueue work, they never synchronise;
+ *   - return value 0 = enqueued, <0 = error (NERF_E_*); nerf_last_error() gives the text
+ *     of the last error raised on the calling thread;
+ *   - all arithmetic is fp32 (dense layers on v_mfma_f32_32x32x2_f32).
+ *
+ * Each entry point names the reference code it replaces (path:line in the reference
+ * repository).
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_ABI_VERSION 1
+
+#define NERF_OK 0
+#define NERF_E_ARG (-1)      /* bad shape / size / unsupported configuration */
+#define NERF_E_NULL (-2)     /* required pointer is NULL */
+#define NERF_E_LAUNCH (-3)   /* HIP reported a launch or runtime error */
+
+#define NERF_MODEL_NERF 0    /* nerf/models.py:9-75   (ReLU MLP, positional encoding) */
+#define NERF_MODEL_SIREN 1   /* nerf/models.py:130-203 (sine MLP) */
+
+int nerf_abi_version(void);
+const char* nerf_last_error(void);
+
+/* ---- sampling: nerf/rendering.py:6-27 (stratified_sampling) and :54-57 (deltas) -------
+ * t[s] = lo[s] + (hi[s]-lo[s])*u[s] over the S+1 edges of linspace(near, far, S+1), bit-exact
+ * with ATen's CPU fp32 linspace (two-sided, one fused rounding per edge);
+ * deltas[s] = t[s+1]-t[s], deltas[S-1] = 1e10.  u, t, deltas: [S].  deltas may be NULL. */
+int nerf_stratified_t(double near, double far, int S, const float* u, float* t, float* deltas, void* stream);
+
+/* ---- sample positions: nerf/rendering.py:59-62 (+ :82 when normalize != 0) -------------
+ * pos[r,s,:] = o[r,:] + t[s]*d[r,:]; with normalize: 2*(pos-near)/(far-near)-1 in the
+ * reference's operation order (bit-exact with the CPU reference).  pos: [R,S,3]. */
+int nerf_sample_positions(const float* rays_o, const float* rays_d, const float* t, int64_t R, int S,
+                          int normalize, double near, double far, float* pos, void* stream);
+
+/* ---- positional encoding: nerf/encoding.py:4-20 ----------------------------------------
+ * out[m,:] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)], x: [M,D],
+ * out: [M, D*(1+2L)], each sin/cos block D wide.  1 <= D <= 4, 0 <= L <= 16. */
+int nerf_posenc_fwd(const float* x, int64_t M, int D, int L, float* out, void* stream);
+
+/* ---- compositing: nerf/rendering.py:110-153 (compute_accumulated_transmittance,
+ * composite_volume) ------------------------------------------------------------------------
+ * colors [R,S,3], densities [R,S], deltas [S] -> rgb [R,3]; optional outputs (NULL to skip):
+ * weights [R,S] (= T_excl(1-alpha)*alpha), depth [R] (= sum w*t, needs t [S]; no reference
+ * counterpart), acc [R] (= sum w).  One ray per wavefront; 1 <= S <= 1024. */
+int nerf_composite_fwd(const float* colors, const float* densities, const float* deltas, const float* t,
+                       int64_t R, int S, int white_background, float* rgb, float* weights, float* depth,
+                       float* acc, void* stream);
+
+/* Gradient of nerf_composite_fwd's rgb wrt colors and densities (what autograd derives for
+ * nerf/rendering.py:143-151, including ATen's zero-safe cumprod backward).
+ * grad_rgb [R,3] -> dcolors [R,S,3], ddensities [R,S]. */
+int nerf_composite_bwd(const float* colors, const float* densities, const float* deltas, int64_t R, int S,
+                       int white_background, const float* grad_rgb, float* dcolors, float* ddensities,
+                       void* stream);
+
+/* ---- MLP: nerf/models.py NeRF.forward :62-75, Siren.forward :185-203 ---------------------
+ * Only the architecture the reference's callers build is supported: hidden 256, 10/4
+ * encoding frequencies, 8 Siren layers, w0 30 / 1, sigma_mul 10, rgb_mul 1 (train.py:101-103).
+ *
+ * Parameters are exchanged in the order of the reference module's state_dict
+ * (24 tensors, [out,in] row-major weights): `params` is a HOST array of 24 device pointers.
+ */
+#define NERF_NUM_PARAM_TENSORS 24
+
+size_t nerf_mlp_param_floats(int model);                       /* 661636 (NeRF) / 564356 (Siren) */
+size_t nerf_mlp_packed_floats(int model);                      /* size of the packed weight image */
+size_t nerf_mlp_fwd_workspace_floats(int model, int64_t M);    /* activations kept for backward */
+size_t nerf_mlp_bwd_workspace_floats(int model, int64_t M);    /* layer gradients + wgrad partials */
+
+/* Re-order the 24 parameter tensors into the MFMA-fragment-ordered image the fused kernels
+ * stream (forward image [k/8][n][8] and its transpose for the backward data gradient).
+ * Must be re-run whenever a parameter changes. */
+int nerf_mlp_pack(int model, const float* const* params, float* packed, void* stream);
+
+/* Fused encode + MLP forward over M samples.
+ * Inputs, one of:
+ *   points != NULL: points [M,3] (already normalised), dirs [M,3]            (models.py forward)
+ *   points == NULL: rays_o, rays_d [R,3], t [S], M = R*S; sample m belongs to ray m/S and
+ *                   the position is generated and normalised in registers as
+ *                   nerf/rendering.py:59-62,82 would (never materialised in HBM).
+ * Outputs: colors [M,3], density [M].
+ * workspace: NULL for inference; else nerf_mlp_fwd_workspace_floats(model, M) floats that
+ * nerf_mlp_bwd reads. */
+int nerf_mlp_fwd(int model, const float* packed, int64_t M, const float* points, const float* dirs,
+                 const float* rays_o, const float* rays_d, const float* t, int S, double near, double far,
+                 float* colors, float* density, float* workspace, void* stream);
+
+/* Backward of nerf_mlp_fwd wrt the 24 parameter tensors.
+ * dcolors [M,3], ddensity [M]: upstream gradients; colors: the forward's output.
+ * grads: flat buffer of nerf_mlp_param_floats(model) floats, tensors laid out back to back
+ * in state_dict order (OVERWRITTEN, not accumulated).
+ * bwd_workspace: nerf_mlp_bwd_workspace_floats(model, M) floats of scratch. */
+int nerf_mlp_bwd(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
+                 const float* colors, const float* fwd_workspace, float* bwd_workspace, float* grads,
+                 void* stream);
+
+/* ---- optimizer: torch.optim.Adam as train.py:123,182 uses it (no weight decay, no amsgrad) --
+ * One launch over a flat parameter buffer: p, g, m, v [n].  step is 1-based. */
+int nerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, double lr, double beta1,
+                   double beta2, double eps, double grad_scale, void* stream);
+
+/* ---- hierarchical sampling (no counterpart in the reference; canonical NeRF sample_pdf) ----
+ * nerf_weights_to_cdf: weights [R,B] -> cdf [R,B+1] = [0, cumsum((w+1e-5)/sum(w+1e-5))].
+ * nerf_sample_pdf: bins [R,B+1], cdf [R,B+1], u [R,N] -> samples [R,N] (linear interpolation
+ * inside the bin) and idx [R,N] (int32: searchsorted(cdf, u, right=True); a pure comparison
+ * result, bit-exact for identical cdf and u). */
+int nerf_weights_to_cdf(const float* weights, int64_t R, int B, float* cdf, void* stream);
+int nerf_sample_pdf(const float* bins, const float* cdf, const float* u, int64_t R, int B, int N,
+                    float* samples, int32_t* idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

@@ -1,0 +1,40 @@
+// Shared host/device helpers for libnerf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/nerf_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// thread-local text of the last error, read through nerf_last_error()
+extern thread_local char g_nerf_err[256];
+
+static inline int nerf_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_nerf_err, sizeof(g_nerf_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define NERF_REQUIRE(cond, ...)                              \
+    do {                                                     \
+        if (!(cond)) return nerf_fail(NERF_E_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define NERF_REQUIRE_PTR(p)                                                   \
+    do {                                                                      \
+        if ((p) == nullptr) return nerf_fail(NERF_E_NULL, "%s is NULL", #p);  \
+    } while (0)
+
+static inline int nerf_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nerf_fail(NERF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return NERF_OK;
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

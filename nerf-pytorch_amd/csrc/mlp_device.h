@@ -1,0 +1,165 @@
+// Device building blocks of the fused MLP kernels (gfx950, wave64, fp32 MFMA).
+//
+// Tile geometry: a workgroup of 4 waves owns 64 samples.  The current layer input
+// lives in LDS as act[64][LDA] (row = sample, LDA = 260 floats so that the 16-byte A
+// fragment reads of 32 consecutive rows fall on distinct banks).  Wave w computes all
+// 64 rows x columns [w*32*NT, (w+1)*32*NT) of the layer output with
+// v_mfma_f32_32x32x2_f32: acc[mi][ni] is the 32x32 tile (rows 32*mi.., cols ncol0+32*ni..).
+//
+// MFMA operand maps (32x32x2 f32): lane l supplies A[row l&31][k l>>5] and
+// B[k l>>5][col l&31]; accumulator register g of lane l is
+// D[row (g&3) + 8*(g>>2) + 4*(l>>5)][col l&31].
+// One 16-byte fragment load gives a lane the values k = 8*kb + 4*(l>>5) + j, j = 0..3;
+// MFMA step j therefore contracts k = 8*kb + j and 8*kb + 4 + j -- the order inside a K
+// block is permuted identically for A and B, which leaves the sum unchanged.
+#pragma once
+#include "common.h"
+#include "mlp_layout.h"
+#include "sincos.h"
+
+namespace dev {
+
+constexpr int LDA = 260;
+constexpr int ACT_FLOATS = lay::TILE * LDA;
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIN = 2 };
+
+__device__ __forceinline__ f32x16 splat16(float v) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = v;
+    return r;
+}
+
+// acc[mi][ni] (+)= act[rows 32*mi.., k < 8*kb_count] * img, img = packed image with `n_img`
+// columns per K block; this wave's first column is ncol0.
+template <int NT>
+__device__ __forceinline__ void mma_layer(const float* act, const float* __restrict__ img, int n_img, int kb_count,
+                                          int ncol0, int lane, f32x16 (&acc)[2][NT]) {
+    const int r = lane & 31, h = lane >> 5;
+    const float* a_ptr = act + r * LDA + 4 * h;
+    const float* b_ptr = img + (size_t)(ncol0 + r) * 8 + 4 * h;
+    const size_t kb_stride = (size_t)n_img * 8;
+    f32x4 a_cur[2], b_cur[NT], a_nxt[2], b_nxt[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) b_cur[ni] = *reinterpret_cast<const f32x4*>(b_ptr + ni * 256);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a_cur[mi] = *reinterpret_cast<const f32x4*>(a_ptr + mi * 32 * LDA);
+    for (int kb = 0; kb < kb_count; ++kb) {
+        const int kn = (kb + 1 < kb_count) ? kb + 1 : kb;  // clamped prefetch of the next K block
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+            b_nxt[ni] = *reinterpret_cast<const f32x4*>(b_ptr + kn * kb_stride + ni * 256);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a_nxt[mi] = *reinterpret_cast<const f32x4*>(a_ptr + mi * 32 * LDA + kn * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mi][j], b_cur[ni][j], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) b_cur[ni] = b_nxt[ni];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a_cur[mi] = a_nxt[mi];
+    }
+}
+
+// accumulators start at the bias of their column
+template <int NT>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[2][NT], const float* __restrict__ bias, int ncol0, int lane) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const float b = bias ? bias[ncol0 + 32 * ni + (lane & 31)] : 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = splat16(b);
+    }
+}
+
+__device__ __forceinline__ int acc_row(int mi, int g, int lane) { return 32 * mi + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5); }
+
+// Forward epilogue: activation, write the tile back to LDS as the next layer's input.
+// The post-activation tile itself goes to the workspace afterwards through store_tile
+// (whole rows, 16 B per lane); for sine layers (training) the derivative cos(z) has no LDS
+// home and is stored from the accumulator layout: gcos = row 0 of this tile, [64][ldg].
+template <int NT, int ACT, bool STORE_COS>
+__device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], int ncol0, int lane,
+                                             float* __restrict__ gcos, int ldg) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int col = ncol0 + 32 * ni + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = acc_row(mi, g, lane);
+                float v = acc[mi][ni][g];
+                float c = 0.f;
+                if constexpr (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                if constexpr (ACT == ACT_SIN) {
+                    float s;
+                    nerf_sincosf(v, &s, &c);
+                    v = s;
+                }
+                act[row * LDA + col] = v;
+                if constexpr (STORE_COS && ACT == ACT_SIN) gcos[(size_t)row * ldg + col] = c;
+            }
+        }
+}
+
+// Backward epilogue: dX = acc (+ rank-1 term) times the activation derivative, written to
+// LDS (next layer's dY) and to the backward workspace (for the weight gradient).
+//   MASK 1: derivative = (hsrc > 0)         (ReLU; hsrc = the stored post-activation input)
+//   MASK 2: derivative = hsrc               (sine; hsrc = stored w0*cos(w0 z))
+//   MASK 0: none
+template <int NT, int MASK, bool RANK1>
+__device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], int ncol0, int lane,
+                                             const float* __restrict__ hsrc, float* __restrict__ gout, int ldg,
+                                             const float* dsig_lds, const float* __restrict__ sigw) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int col = ncol0 + 32 * ni + (lane & 31);
+            float sw = 0.f;
+            if constexpr (RANK1) sw = sigw[col];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = acc_row(mi, g, lane);
+                float v = acc[mi][ni][g];
+                if constexpr (RANK1) v = fmaf(dsig_lds[row], sw, v);
+                if constexpr (MASK == 1) v = hsrc[(size_t)row * ldg + col] > 0.0f ? v : 0.0f;
+                if constexpr (MASK == 2) v = v * hsrc[(size_t)row * ldg + col];
+                act[row * LDA + col] = v;
+                gout[(size_t)row * ldg + col] = v;
+            }
+        }
+}
+
+// positional encoding of one coordinate into a tile row: writes x and L sin/cos pairs.
+// `dst` points at the row start; column layout of nerf/encoding.py (blocks of 3).
+template <int L>
+__device__ __forceinline__ void encode_axis(float* dst, int axis, float x) {
+    dst[axis] = x;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        float s, c;
+        nerf_sincosf(__fmul_rn((float)(1 << j), x), &s, &c);
+        dst[3 + 6 * j + axis] = s;
+        dst[3 + 6 * j + 3 + axis] = c;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// copy `cols` (multiple of 4) columns of the 64-row LDS tile to global rows of `ldg` floats
+__device__ __forceinline__ void store_tile(const float* act, int cols, float* __restrict__ g, int ldg, int tid) {
+    const int c4n = cols >> 2;
+    for (int i = tid; i < lay::TILE * c4n; i += 256) {
+        const int row = i / c4n, c4 = i - row * c4n;
+        *reinterpret_cast<f32x4*>(g + (size_t)row * ldg + 4 * c4) = *reinterpret_cast<const f32x4*>(act + row * LDA + 4 * c4);
+    }
+}
+
+}  // namespace dev

@@ -1,0 +1,477 @@
+// Weight packing and the fused encode + MLP forward kernels.
+// Replaces nerf/models.py NeRF.forward (:62-75) and Siren.forward (:185-203), with the
+// sample-position generation and normalisation of nerf/rendering.py:59-62,82 folded in when
+// the caller passes rays instead of points.
+#include "mlp_device.h"
+
+using namespace dev;
+
+// =====================================================================================
+// packing
+// =====================================================================================
+namespace {
+
+struct PackJob {
+    int tensor;        // index into the 24 parameter pointers
+    int src_off;       // element offset inside the tensor
+    int sn, sk;        // strides of the image's N and K index in the source
+    int N, K, KB;      // KB == 0: plain copy of N floats
+    unsigned dst_off;  // float offset inside the packed image
+};
+constexpr int kMaxPackJobs = 48;
+struct PackArgs {
+    const float* src[NERF_NUM_PARAM_TENSORS];
+    float* dst;
+    int njobs;
+    PackJob jobs[kMaxPackJobs];
+};
+
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+    const PackJob j = a.jobs[blockIdx.x];
+    const float* __restrict__ src = a.src[j.tensor] + j.src_off;
+    float* __restrict__ dst = a.dst + j.dst_off;
+    if (j.KB == 0) {
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < j.N; i += gridDim.y * 256) dst[i] = src[i];
+        return;
+    }
+    const int total = j.KB * j.N * 8;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < total; i += gridDim.y * 256) {
+        const int jj = i & 7, n = (i >> 3) % j.N, kb = (i >> 3) / j.N;
+        const int k = kb * 8 + jj;
+        dst[i] = (k < j.K) ? src[(size_t)n * j.sn + (size_t)k * j.sk] : 0.0f;
+    }
+}
+
+void add_fwd(PackArgs& a, int tensor, int ld, int col0, int row0, int N, int K, size_t dst) {
+    // forward image of rows row0..row0+N, columns col0..col0+K of a [*, ld] weight
+    a.jobs[a.njobs++] = PackJob{tensor, row0 * ld + col0, ld, 1, N, K, (K + 7) / 8, (unsigned)dst};
+}
+void add_bwd(PackArgs& a, int tensor, int ld, int col0, int row0, int Nin, int Kout, size_t dst) {
+    // transposed image: reduce over rows row0..row0+Kout, image columns = weight columns col0..col0+Nin
+    a.jobs[a.njobs++] = PackJob{tensor, row0 * ld + col0, 1, ld, Nin, Kout, (Kout + 7) / 8, (unsigned)dst};
+}
+void add_copy(PackArgs& a, int tensor, int off, int count, size_t dst) {
+    a.jobs[a.njobs++] = PackJob{tensor, off, 0, 0, count, 0, 0, (unsigned)dst};
+}
+
+void build_nerf_jobs(PackArgs& a) {
+    using namespace lay;
+    using namespace lay::nerf;
+    add_fwd(a, 0, PE, 0, 0, H, PE, F_L0);
+    for (int l = 1; l <= 4; ++l) add_fwd(a, 2 * l, H, 0, 0, H, H, F_L1 + (size_t)(l - 1) * img(H, H));
+    add_fwd(a, 10, H + PE, 0, 0, H, H, F_L5A);
+    add_fwd(a, 10, H + PE, H, 0, H, PE, F_L5B);
+    for (int l = 6; l <= 8; ++l) add_fwd(a, 2 * l, H, 0, 0, H, H, F_L6 + (size_t)(l - 6) * img(H, H));
+    add_fwd(a, 18, H, 0, 0, H, H, F_L9);
+    add_fwd(a, 20, H + DE, 0, 0, HH, H, F_L10A);
+    add_fwd(a, 20, H + DE, H, 0, HH, DE, F_L10B);
+    add_copy(a, 18, H * H, H, SIGW);
+    add_copy(a, 22, 0, 3 * HH, W11);
+    for (int l = 0; l <= 8; ++l) add_copy(a, 2 * l + 1, 0, H, BIAS + (size_t)l * H);
+    add_copy(a, 19, 0, H, BIAS + 9 * (size_t)H);
+    add_copy(a, 19, H, 1, BIAS_SIG);
+    add_copy(a, 21, 0, HH, BIAS10);
+    add_copy(a, 23, 0, 3, BIAS11);
+    add_bwd(a, 20, H + DE, 0, 0, H, HH, D10);
+    add_bwd(a, 18, H, 0, 0, H, H, d_img(9));
+    for (int l = 8; l >= 6; --l) add_bwd(a, 2 * l, H, 0, 0, H, H, d_img(l));
+    add_bwd(a, 10, H + PE, 0, 0, H, H, d_img(5));
+    for (int l = 4; l >= 1; --l) add_bwd(a, 2 * l, H, 0, 0, H, H, d_img(l));
+}
+
+void build_siren_jobs(PackArgs& a) {
+    using namespace lay;
+    using namespace lay::siren;
+    add_copy(a, 0, 0, H * 3, W0);
+    for (int l = 1; l <= 7; ++l) add_fwd(a, 2 * l, H, 0, 0, H, H, F_L1 + (size_t)(l - 1) * img(H, H));
+    add_fwd(a, 18, H, 0, 0, H, H, F_FEAT);
+    add_fwd(a, 20, H + DE, 0, 0, HH, H, F_RGBA);
+    add_fwd(a, 20, H + DE, H, 0, HH, DE, F_RGBB);
+    add_copy(a, 16, 0, H, SIGW);
+    add_copy(a, 22, 0, 3 * HH, WOUT);
+    for (int l = 0; l <= 7; ++l) add_copy(a, 2 * l + 1, 0, H, BIAS + (size_t)l * H);
+    add_copy(a, 19, 0, H, BIAS + 8 * (size_t)H);
+    add_copy(a, 17, 0, 1, BIAS_SIG);
+    add_copy(a, 21, 0, HH, BIAS_RGB);
+    add_copy(a, 23, 0, 3, BIAS_OUT);
+    add_bwd(a, 20, H + DE, 0, 0, H, HH, D_RGB);
+    add_bwd(a, 18, H, 0, 0, H, H, D_FEAT);
+    for (int l = 7; l >= 1; --l) add_bwd(a, 2 * l, H, 0, 0, H, H, d_img(l));
+}
+
+}  // namespace
+
+extern "C" size_t nerf_mlp_param_floats(int model) {
+    return model == NERF_MODEL_NERF ? lay::nerf::PARAM_FLOATS : model == NERF_MODEL_SIREN ? lay::siren::PARAM_FLOATS : 0;
+}
+extern "C" size_t nerf_mlp_packed_floats(int model) {
+    return model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS : model == NERF_MODEL_SIREN ? lay::siren::PACKED_FLOATS : 0;
+}
+extern "C" size_t nerf_mlp_fwd_workspace_floats(int model, int64_t M) {
+    if (M < 0) return 0;
+    const size_t mp = lay::padded_samples(M);
+    return model == NERF_MODEL_NERF ? mp * lay::nerf::WS_PER_SAMPLE : model == NERF_MODEL_SIREN ? mp * lay::siren::WS_PER_SAMPLE : 0;
+}
+extern "C" size_t nerf_mlp_bwd_workspace_floats(int model, int64_t M) {
+    if (M < 0) return 0;
+    const size_t mp = lay::padded_samples(M);
+    const size_t per = model == NERF_MODEL_NERF ? lay::nerf::BW_PER_SAMPLE : model == NERF_MODEL_SIREN ? lay::siren::BW_PER_SAMPLE : 0;
+    return per ? mp * per + lay::SLAB_FLOATS : 0;
+}
+
+extern "C" int nerf_mlp_pack(int model, const float* const* params, float* packed, void* stream) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "nerf_mlp_pack: unknown model %d", model);
+    NERF_REQUIRE_PTR(params);
+    NERF_REQUIRE_PTR(packed);
+    PackArgs a;
+    for (int i = 0; i < NERF_NUM_PARAM_TENSORS; ++i) {
+        if (!params[i]) return nerf_fail(NERF_E_NULL, "nerf_mlp_pack: params[%d] is NULL", i);
+        a.src[i] = params[i];
+    }
+    a.dst = packed;
+    a.njobs = 0;
+    if (model == NERF_MODEL_NERF) build_nerf_jobs(a); else build_siren_jobs(a);
+    pack_kernel<<<dim3(a.njobs, 32), 256, 0, (hipStream_t)stream>>>(a);
+    return nerf_check_launch("nerf_mlp_pack");
+}
+
+// =====================================================================================
+// fused forward
+// =====================================================================================
+namespace {
+
+struct FwdArgs {
+    const float* pk;
+    int64_t M;
+    size_t Mp;
+    const float* points;
+    const float* dirs;
+    const float* rays_o;
+    const float* rays_d;
+    const float* t;
+    int S;
+    float nearf, spanf;
+    float* colors;
+    float* density;
+    float* ws;
+};
+
+constexpr int XIN_FLOATS = lay::TILE * 8;
+constexpr int FWD_LDS_BYTES = (ACT_FLOATS + XIN_FLOATS + lay::TILE) * 4;
+
+__device__ __forceinline__ float norm_coord(float p, float nearf, float spanf) {
+    return __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(p, nearf)), spanf), 1.0f);
+}
+
+// xin[s][0..2] = normalised position, xin[s][3..5] = direction (zeros beyond M)
+__device__ __forceinline__ void load_inputs(const FwdArgs& a, size_t m0, float* xin, int tid) {
+    if (tid < lay::TILE) {
+        const size_t m = m0 + tid;
+        float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+        if (m < (size_t)a.M) {
+            if (a.points) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { x[c] = a.points[m * 3 + c]; d[c] = a.dirs[m * 3 + c]; }
+            } else {
+                const size_t r = m / (size_t)a.S;
+                const float ts = a.t[m - r * (size_t)a.S];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    d[c] = a.rays_d[r * 3 + c];
+                    x[c] = norm_coord(__fadd_rn(a.rays_o[r * 3 + c], __fmul_rn(ts, d[c])), a.nearf, a.spanf);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xin[tid * 8 + c] = x[c]; xin[tid * 8 + 3 + c] = d[c]; }
+    }
+}
+
+__device__ __forceinline__ void encode_pe(float* act, const float* xin, int tid) {
+    const int smp = tid >> 2, q = tid & 3;
+    if (q < 3) encode_axis<10>(act + smp * LDA, q, xin[smp * 8 + q]);
+    else act[smp * LDA + 63] = 0.0f;
+}
+__device__ __forceinline__ void encode_de(float* act, const float* xin, int tid) {
+    const int smp = tid >> 2, q = tid & 3;
+    if (q < 3) encode_axis<4>(act + smp * LDA, q, xin[smp * 8 + 3 + q]);
+    else {
+#pragma unroll
+        for (int c = lay::DE; c < lay::DE_P; ++c) act[smp * LDA + c] = 0.0f;
+    }
+}
+
+// dot of each tile row (first 256 columns) with a 256-vector; 4 threads per sample
+__device__ __forceinline__ float row_dot256(const float* act, const float* __restrict__ w, int tid) {
+    const int smp = tid >> 2, q = tid & 3;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = 4 * (4 * i + q);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(act + smp * LDA + k);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+        s += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    return s;
+}
+
+// 128 -> 3 output layer + sigmoid; 4 threads per sample over act[:, 0:128]
+__device__ __forceinline__ void head_out(const float* act, const float* __restrict__ w, const float* __restrict__ b,
+                                         float rgb_mul, float dens, size_t m0, int64_t M, float* __restrict__ colors,
+                                         float* __restrict__ density, int tid) {
+    const int smp = tid >> 2, q = tid & 3;
+    float z[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = 4 * (4 * i + q);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(act + smp * LDA + k);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c * lay::HH + k);
+            z[c] += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        z[c] += __shfl_xor(z[c], 1);
+        z[c] += __shfl_xor(z[c], 2);
+    }
+    const size_t m = m0 + smp;
+    if (q == 0 && m < (size_t)M) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) colors[m * 3 + c] = sigmoidf_((z[c] + b[c]) * rgb_mul);
+        density[m] = dens;
+    }
+}
+
+// one 256 -> 256 layer on the tile: bias, MFMA loop, barrier, epilogue, barrier
+template <int ACT, bool TRAIN>
+__device__ __forceinline__ void hidden_layer(float* act, const float* __restrict__ img, int kb_count,
+                                             const float* __restrict__ bias, int ncol0, int tid, float* gout,
+                                             float* gcos) {
+    const int lane = tid & 63;
+    f32x16 acc[2][2];
+    init_bias<2>(acc, bias, ncol0, lane);
+    mma_layer<2>(act, img, lay::H, kb_count, ncol0, lane, acc);
+    __syncthreads();
+    fwd_epilogue<2, ACT, TRAIN>(act, acc, ncol0, lane, gcos, lay::H);
+    __syncthreads();
+    // the next layer only reads the tile, so this copy needs no barrier of its own
+    if constexpr (TRAIN) store_tile(act, lay::H, gout, lay::H, tid);
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
+    using namespace lay;
+    using namespace lay::nerf;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* act = smem;
+    float* xin = smem + ACT_FLOATS;
+    float* sraw_s = xin + XIN_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t m0 = (size_t)blockIdx.x * TILE;
+    const float* __restrict__ pk = a.pk;
+    float* ws = a.ws;
+    const size_t Mp = a.Mp;
+    auto wsp = [&](size_t off, int width) -> float* { return TRAIN ? ws + off * Mp + m0 * width : nullptr; };
+
+    load_inputs(a, m0, xin, tid);
+    __syncthreads();
+    encode_pe(act, xin, tid);
+    __syncthreads();
+    if constexpr (TRAIN) store_tile(act, PE_P, wsp(WS_PE, PE_P), PE_P, tid);
+
+    const int ncol0 = wave * 64;
+    // L0: K 64
+    hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L0, PE_P / 8, pk + BIAS, ncol0, tid, wsp(WS_H, H), nullptr);
+    // L1..L4
+    for (int l = 1; l <= 4; ++l)
+        hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
+                                      tid, wsp(WS_H + (size_t)l * H, H), nullptr);
+    // L5: [h4 | pe] in two passes over the same accumulators
+    {
+        f32x16 acc[2][2];
+        init_bias<2>(acc, pk + BIAS + 5 * H, ncol0, lane);
+        mma_layer<2>(act, pk + F_L5A, H, H / 8, ncol0, lane, acc);
+        __syncthreads();
+        encode_pe(act, xin, tid);
+        __syncthreads();
+        mma_layer<2>(act, pk + F_L5B, H, PE_P / 8, ncol0, lane, acc);
+        __syncthreads();
+        fwd_epilogue<2, ACT_RELU, false>(act, acc, ncol0, lane, nullptr, H);
+        __syncthreads();
+        if constexpr (TRAIN) store_tile(act, H, wsp(WS_H + 5 * (size_t)H, H), H, tid);
+    }
+    // L6..L8
+    for (int l = 6; l <= 8; ++l)
+        hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L6 + (size_t)(l - 6) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
+                                      tid, wsp(WS_H + (size_t)l * H, H), nullptr);
+    // L9: 256 feature columns on MFMA, density column on the VALU
+    {
+        f32x16 acc[2][2];
+        init_bias<2>(acc, pk + BIAS + 9 * H, ncol0, lane);
+        mma_layer<2>(act, pk + F_L9, H, H / 8, ncol0, lane, acc);
+        const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
+        if ((tid & 3) == 0) {
+            sraw_s[tid >> 2] = s;
+            if constexpr (TRAIN) ws[WS_SRAW * Mp + m0 + (tid >> 2)] = s;
+        }
+        __syncthreads();
+        fwd_epilogue<2, ACT_NONE, false>(act, acc, ncol0, lane, nullptr, H);
+        __syncthreads();
+        if constexpr (TRAIN) store_tile(act, H, wsp(WS_F, H), H, tid);
+    }
+    // L10: [f | de] -> 128, two passes
+    {
+        const int nc = wave * 32;
+        f32x16 acc[2][1];
+        init_bias<1>(acc, pk + BIAS10, nc, lane);
+        mma_layer<1>(act, pk + F_L10A, HH, H / 8, nc, lane, acc);
+        __syncthreads();
+        encode_de(act, xin, tid);
+        __syncthreads();
+        if constexpr (TRAIN) store_tile(act, DE_P, wsp(WS_DE, DE_P), DE_P, tid);
+        mma_layer<1>(act, pk + F_L10B, HH, DE_P / 8, nc, lane, acc);
+        __syncthreads();
+        fwd_epilogue<1, ACT_RELU, false>(act, acc, nc, lane, nullptr, HH);
+        __syncthreads();
+        if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
+    }
+    // L11 + sigmoid, density = relu(raw)
+    head_out(act, pk + W11, pk + BIAS11, 1.0f, fmaxf(sraw_s[tid >> 2], 0.0f), m0, a.M, a.colors, a.density, tid);
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
+    using namespace lay;
+    using namespace lay::siren;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* act = smem;
+    float* xin = smem + ACT_FLOATS;
+    float* sraw_s = xin + XIN_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t m0 = (size_t)blockIdx.x * TILE;
+    const float* __restrict__ pk = a.pk;
+    float* ws = a.ws;
+    const size_t Mp = a.Mp;
+    auto wsp = [&](size_t off, int width) -> float* { return TRAIN ? ws + off * Mp + m0 * width : nullptr; };
+
+    load_inputs(a, m0, xin, tid);
+    __syncthreads();
+    if constexpr (TRAIN) {
+        if (tid < TILE) {
+            f32x4 v = {xin[tid * 8], xin[tid * 8 + 1], xin[tid * 8 + 2], 0.0f};
+            *reinterpret_cast<f32x4*>(ws + WS_X * Mp + (m0 + tid) * 4) = v;
+        }
+    }
+    // layer 0 (3 -> 256, sin(30 z)) on the VALU: thread = output column
+    {
+        const float w0 = pk[W0 + tid * 3], w1 = pk[W0 + tid * 3 + 1], w2 = pk[W0 + tid * 3 + 2], b = pk[BIAS + tid];
+        float* gh = wsp(WS_H, H);
+        float* gc = wsp(WS_C, H);
+        for (int s = 0; s < TILE; ++s) {
+            const float z = fmaf(xin[s * 8 + 2], w2, fmaf(xin[s * 8 + 1], w1, fmaf(xin[s * 8], w0, b)));
+            float sn, cs;
+            nerf_sincosf(__fmul_rn(30.0f, z), &sn, &cs);
+            act[s * LDA + tid] = sn;
+            if constexpr (TRAIN) {
+                gh[(size_t)s * H + tid] = sn;
+                gc[(size_t)s * H + tid] = 30.0f * cs;
+            }
+        }
+    }
+    __syncthreads();
+    const int ncol0 = wave * 64;
+    for (int l = 1; l <= 7; ++l)
+        hidden_layer<ACT_SIN, TRAIN>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), H / 8, pk + BIAS + l * H, ncol0, tid,
+                                     wsp(WS_H + (size_t)l * H, H), wsp(WS_C + (size_t)l * H, H));
+    // feature_remap on MFMA, density branch on the VALU (both read h7)
+    {
+        f32x16 acc[2][2];
+        init_bias<2>(acc, pk + BIAS + 8 * H, ncol0, lane);
+        mma_layer<2>(act, pk + F_FEAT, H, H / 8, ncol0, lane, acc);
+        const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
+        if ((tid & 3) == 0) {
+            sraw_s[tid >> 2] = s;
+            if constexpr (TRAIN) ws[WS_SRAW * Mp + m0 + (tid >> 2)] = s;
+        }
+        __syncthreads();
+        fwd_epilogue<2, ACT_NONE, false>(act, acc, ncol0, lane, nullptr, H);
+        __syncthreads();
+        if constexpr (TRAIN) store_tile(act, H, wsp(WS_F, H), H, tid);
+    }
+    {
+        const int nc = wave * 32;
+        f32x16 acc[2][1];
+        init_bias<1>(acc, pk + BIAS_RGB, nc, lane);
+        mma_layer<1>(act, pk + F_RGBA, HH, H / 8, nc, lane, acc);
+        __syncthreads();
+        encode_de(act, xin, tid);
+        __syncthreads();
+        if constexpr (TRAIN) store_tile(act, DE_P, wsp(WS_DE, DE_P), DE_P, tid);
+        mma_layer<1>(act, pk + F_RGBB, HH, DE_P / 8, nc, lane, acc);
+        __syncthreads();
+        fwd_epilogue<1, ACT_SIN, TRAIN>(act, acc, nc, lane, wsp(WS_CG, HH), HH);
+        __syncthreads();
+        if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
+    }
+    head_out(act, pk + WOUT, pk + BIAS_OUT, 1.0f, fmaxf(sraw_s[tid >> 2], 0.0f) * 10.0f, m0, a.M, a.colors, a.density,
+             tid);
+}
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return nerf_fail(NERF_E_LAUNCH, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
+    return NERF_OK;
+}
+
+}  // namespace
+
+extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const float* points, const float* dirs,
+                            const float* rays_o, const float* rays_d, const float* t, int S, double near, double far,
+                            float* colors, float* density, float* workspace, void* stream) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "nerf_mlp_fwd: unknown model %d", model);
+    NERF_REQUIRE(M >= 0, "nerf_mlp_fwd: M=%lld < 0", (long long)M);
+    if (M == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(packed);
+    NERF_REQUIRE_PTR(colors);
+    NERF_REQUIRE_PTR(density);
+    if (points) {
+        NERF_REQUIRE_PTR(dirs);
+    } else {
+        NERF_REQUIRE_PTR(rays_o);
+        NERF_REQUIRE_PTR(rays_d);
+        NERF_REQUIRE_PTR(t);
+        NERF_REQUIRE(S >= 1 && M % S == 0, "nerf_mlp_fwd: ray mode needs M (%lld) to be a multiple of S (%d)",
+                     (long long)M, S);
+    }
+    const size_t mp = lay::padded_samples(M);
+    const size_t tiles = mp / lay::TILE;
+    NERF_REQUIRE(tiles < (1ull << 31), "nerf_mlp_fwd: too many samples");
+    FwdArgs a{packed, M, mp, points, dirs, rays_o, rays_d, t, S, (float)near, (float)(far - near), colors, density, workspace};
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (model == NERF_MODEL_NERF) {
+        if (workspace) {
+            if ((rc = set_lds(nerf_fwd_kernel<true>, FWD_LDS_BYTES))) return rc;
+            nerf_fwd_kernel<true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+        } else {
+            if ((rc = set_lds(nerf_fwd_kernel<false>, FWD_LDS_BYTES))) return rc;
+            nerf_fwd_kernel<false><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+        }
+    } else {
+        if (workspace) {
+            if ((rc = set_lds(siren_fwd_kernel<true>, FWD_LDS_BYTES))) return rc;
+            siren_fwd_kernel<true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+        } else {
+            if ((rc = set_lds(siren_fwd_kernel<false>, FWD_LDS_BYTES))) return rc;
+            siren_fwd_kernel<false><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+        }
+    }
+    return nerf_check_launch("nerf_mlp_fwd");
+}

@@ -1,0 +1,214 @@
+// Stratified sampling, sample positions and positional encoding as stand-alone,
+// HBM-bound kernels (the fused MLP kernel generates the same values in registers).
+//
+// Replaces nerf/rendering.py:6-64,82 and nerf/encoding.py:4-20 of the reference.
+#include "common.h"
+#include "sincos.h"
+
+thread_local char g_nerf_err[256] = "";
+
+extern "C" int nerf_abi_version(void) { return NERF_ABI_VERSION; }
+extern "C" const char* nerf_last_error(void) { return g_nerf_err; }
+
+// ---------------------------------------------------------------------------------------
+// linspace edge i of [near, far] with `steps` points, as ATen's CPU fp32 kernel computes
+// it: a fused multiply-add from the nearer end (one rounding).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float linspace_edge(float lo, float hi, float step, int i, int steps) {
+    return (i < steps / 2) ? __fmaf_rn(step, (float)i, lo) : __fmaf_rn(-step, (float)(steps - 1 - i), hi);
+}
+
+__device__ __forceinline__ float strat_t(float lo_end, float hi_end, float step, int s, int S, float u) {
+    const float lo = linspace_edge(lo_end, hi_end, step, s, S + 1);
+    const float hi = linspace_edge(lo_end, hi_end, step, s + 1, S + 1);
+    // lower + (upper - lower) * u with separately rounded mul and add (rendering.py:27)
+    return __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), u));
+}
+
+__global__ void stratified_t_kernel(float lo_end, float hi_end, float step, int S, const float* __restrict__ u,
+                                    float* __restrict__ t, float* __restrict__ deltas) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const float ts = strat_t(lo_end, hi_end, step, s, S, u[s]);
+    t[s] = ts;
+    if (deltas) {
+        if (s + 1 < S) {
+            const float tn = strat_t(lo_end, hi_end, step, s + 1, S, u[s + 1]);
+            deltas[s] = __fsub_rn(tn, ts);
+        } else {
+            deltas[s] = 1e10f;
+        }
+    }
+}
+
+extern "C" int nerf_stratified_t(double near, double far, int S, const float* u, float* t, float* deltas,
+                                 void* stream) {
+    NERF_REQUIRE(S >= 1 && S <= (1 << 20), "nerf_stratified_t: S=%d out of range", S);
+    NERF_REQUIRE_PTR(u);
+    NERF_REQUIRE_PTR(t);
+    const float lo = (float)near, hi = (float)far;
+    const float step = (hi - lo) / (float)S;  // (end-start)/(steps-1) in fp32, steps = S+1
+    stratified_t_kernel<<<(S + 255) / 256, 256, 0, (hipStream_t)stream>>>(lo, hi, step, S, u, t, deltas);
+    return nerf_check_launch("nerf_stratified_t");
+}
+
+// ---------------------------------------------------------------------------------------
+// positions: one thread per sample, 12 B each, a wave writes 768 contiguous bytes
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float normalize_coord(float p, float nearf, float spanf) {
+    // 2*(p-near)/(far-near)-1: sub, mul by 2, true division, sub 1 (rendering.py:82)
+    return __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(p, nearf)), spanf), 1.0f);
+}
+
+__global__ void sample_positions_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                        const float* __restrict__ t, int64_t R, int S, int normalize, float nearf,
+                                        float spanf, float* __restrict__ pos) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= R * S) return;
+    const int64_t r = m / S;
+    const int s = (int)(m - r * S);
+    const float ts = t[s];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float p = __fadd_rn(o[r * 3 + c], __fmul_rn(ts, d[r * 3 + c]));
+        if (normalize) p = normalize_coord(p, nearf, spanf);
+        pos[m * 3 + c] = p;
+    }
+}
+
+extern "C" int nerf_sample_positions(const float* rays_o, const float* rays_d, const float* t, int64_t R, int S,
+                                     int normalize, double near, double far, float* pos, void* stream) {
+    NERF_REQUIRE(R >= 0 && S >= 1, "nerf_sample_positions: bad R=%lld S=%d", (long long)R, S);
+    if (R == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(rays_o);
+    NERF_REQUIRE_PTR(rays_d);
+    NERF_REQUIRE_PTR(t);
+    NERF_REQUIRE_PTR(pos);
+    const int64_t M = R * S;
+    NERF_REQUIRE(ceil_div64(M, 256) < (1ll << 31), "nerf_sample_positions: too many samples");
+    sample_positions_kernel<<<(unsigned)ceil_div64(M, 256), 256, 0, (hipStream_t)stream>>>(
+        rays_o, rays_d, t, R, S, normalize, (float)near, (float)(far - near), pos);
+    return nerf_check_launch("nerf_sample_positions");
+}
+
+// ---------------------------------------------------------------------------------------
+// positional encoding: one thread per (sample, frequency slot, coordinate); slot 0 copies x,
+// slot j>=1 writes sin and cos of 2^(j-1) x.  Full-range sinf/cosf (arguments reach ~1e3 rad).
+// ---------------------------------------------------------------------------------------
+__global__ void posenc_kernel(const float* __restrict__ x, int64_t M, int D, int L, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = D * (L + 1);
+    if (idx >= M * per) return;
+    const int64_t m = idx / per;
+    const int rem = (int)(idx - m * per);
+    const int j = rem / D, c = rem - j * D;
+    const int width = D * (1 + 2 * L);
+    const float v = x[m * D + c];
+    float* row = out + m * width;
+    if (j == 0) {
+        row[c] = v;
+    } else {
+        const float a = __fmul_rn((float)(1u << (j - 1)), v);
+        float sn, cs;
+        nerf_sincosf(a, &sn, &cs);
+        row[D + 2 * D * (j - 1) + c] = sn;
+        row[D + 2 * D * (j - 1) + D + c] = cs;
+    }
+}
+
+extern "C" int nerf_posenc_fwd(const float* x, int64_t M, int D, int L, float* out, void* stream) {
+    NERF_REQUIRE(M >= 0 && D >= 1 && D <= 4 && L >= 0 && L <= 16, "nerf_posenc_fwd: bad M=%lld D=%d L=%d",
+                 (long long)M, D, L);
+    if (M == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(x);
+    NERF_REQUIRE_PTR(out);
+    const int64_t n = M * D * (L + 1);
+    NERF_REQUIRE(ceil_div64(n, 256) < (1ll << 31), "nerf_posenc_fwd: too many elements");
+    posenc_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>(x, M, D, L, out);
+    return nerf_check_launch("nerf_posenc_fwd");
+}
+
+// ---------------------------------------------------------------------------------------
+// inverse-CDF sampling (no reference counterpart; canonical NeRF sample_pdf), in two steps:
+//   weights -> CDF   (normalise w+1e-5, running sum; fp32, tolerance-tested)
+//   (bins, CDF, u) -> right-sided insertion index + interpolated sample; the index is a pure
+//   comparison result, hence bit-exact for an identical CDF and identical draws.
+// One ray per wavefront.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void weights_to_cdf_kernel(const float* __restrict__ w, int64_t R, int B,
+                                                            float* __restrict__ cdf) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    if (r >= R) return;  // no block-wide barrier below: waves are independent
+    const float* wr = w + r * B;
+    float part = 0.f;
+    for (int i = lane; i < B; i += 64) part += wr[i] + 1e-5f;
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    const float tot = part;
+    // each lane owns a contiguous run of ceil(B/64) bins; wave-exclusive scan of run sums
+    const int per = (B + 63) / 64;
+    const int b0 = lane * per;
+    float run = 0.f;
+    for (int i = 0; i < per; ++i)
+        if (b0 + i < B) run += (wr[b0 + i] + 1e-5f) / tot;
+    float inc = run;
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    float acc = inc - run;
+    float* cr = cdf + r * (B + 1);
+    if (lane == 0) cr[0] = 0.f;
+    for (int i = 0; i < per; ++i)
+        if (b0 + i < B) {
+            acc += (wr[b0 + i] + 1e-5f) / tot;
+            cr[b0 + i + 1] = acc;
+        }
+}
+
+extern "C" int nerf_weights_to_cdf(const float* weights, int64_t R, int B, float* cdf, void* stream) {
+    NERF_REQUIRE(R >= 0 && B >= 1, "nerf_weights_to_cdf: bad R=%lld B=%d", (long long)R, B);
+    if (R == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(weights);
+    NERF_REQUIRE_PTR(cdf);
+    weights_to_cdf_kernel<<<(unsigned)ceil_div64(R, 4), 256, 0, (hipStream_t)stream>>>(weights, R, B, cdf);
+    return nerf_check_launch("nerf_weights_to_cdf");
+}
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ bins, const float* __restrict__ cdf,
+                                                        const float* __restrict__ u, int64_t R, int B, int N,
+                                                        float* __restrict__ samples, int32_t* __restrict__ idx_out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * N) return;
+    const int64_t r = e / N;
+    const float* c = cdf + r * (B + 1);
+    const float* bn = bins + r * (B + 1);
+    const float uu = u[e];
+    int lo = 0, hi = B + 1;  // first index with cdf[idx] > uu  (searchsorted right=True)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c[mid] <= uu) lo = mid + 1; else hi = mid;
+    }
+    const int below = max(lo - 1, 0), above = min(lo, B);
+    const float c0 = c[below], c1 = c[above];
+    float den = __fsub_rn(c1, c0);
+    if (den < 1e-5f) den = 1.f;
+    const float tt = __fdiv_rn(__fsub_rn(uu, c0), den);
+    samples[e] = __fadd_rn(bn[below], __fmul_rn(tt, __fsub_rn(bn[above], bn[below])));
+    idx_out[e] = lo;
+}
+
+extern "C" int nerf_sample_pdf(const float* bins, const float* cdf, const float* u, int64_t R, int B, int N,
+                               float* samples, int32_t* idx, void* stream) {
+    NERF_REQUIRE(R >= 0 && B >= 1 && N >= 1, "nerf_sample_pdf: bad R=%lld B=%d N=%d", (long long)R, B, N);
+    if (R == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(bins);
+    NERF_REQUIRE_PTR(cdf);
+    NERF_REQUIRE_PTR(u);
+    NERF_REQUIRE_PTR(samples);
+    NERF_REQUIRE_PTR(idx);
+    NERF_REQUIRE(ceil_div64(R * N, 256) < (1ll << 31), "nerf_sample_pdf: too many samples");
+    sample_pdf_kernel<<<(unsigned)ceil_div64(R * N, 256), 256, 0, (hipStream_t)stream>>>(bins, cdf, u, R, B, N, samples,
+                                                                                      idx);
+    return nerf_check_launch("nerf_sample_pdf");
+}

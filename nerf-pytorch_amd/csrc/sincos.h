@@ -1,0 +1,37 @@
+// fp32 sine/cosine pair with a three-constant Cody-Waite reduction, accurate to about
+// 1 ulp for |x| <= 1e5 (positional-encoding arguments reach 2^9 * |x| ~ 1e3 rad, the first
+// Siren layer ~1e2 rad).  Larger arguments take the math library's full-range path.
+// Host-compilable (plain C++) so that tests can sweep it against double precision.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define NERF_HD __host__ __device__ __forceinline__
+#else
+#define NERF_HD inline
+#endif
+
+NERF_HD void nerf_sincosf(float x, float* sn, float* cs) {
+    if (!(fabsf(x) <= 1.0e5f)) {  // also catches NaN
+        sincosf(x, sn, cs);
+        return;
+    }
+    const float kf = rintf(x * 0.63661977236758134f);  // nearest multiple of pi/2
+    // pi/2 = P1 + P2 + P3; P1 has 8 significant bits, so kf*P1 is exact for |kf| < 2^16
+    float r = fmaf(-kf, 1.5703125f, x);
+    r = fmaf(-kf, 4.837512969970703125e-4f, r);
+    r = fmaf(-kf, 7.54978995489188e-8f, r);
+    const float z = r * r;
+    // minimax polynomials on [-pi/4, pi/4]
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    ps = fmaf(ps * z, r, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    pc = fmaf(pc, z * z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)kf & 3;
+    const float s0 = (q & 1) ? pc : ps;
+    const float c0 = (q & 1) ? ps : pc;
+    *sn = (q & 2) ? -s0 : s0;
+    *cs = ((q + 1) & 2) ? -c0 : c0;
+}

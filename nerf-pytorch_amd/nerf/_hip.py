@@ -1,0 +1,220 @@
+"""ctypes binding of libnerf_hip.so (C ABI declared in include/nerf_hip.h).
+
+There is no CPU fallback: importing this module without the built library, or calling
+an op with a tensor that is not a contiguous fp32 tensor on a HIP device, raises.
+PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnerf_hip.so")
+
+MODEL_NERF = 0
+MODEL_SIREN = 1
+NUM_PARAM_TENSORS = 24
+ABI_VERSION = 1
+
+if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f"{LIB_PATH} is missing: build it with `make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}` "
+        "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_P = c_void_p
+_SIGS = {
+    "nerf_abi_version": (c_int, []),
+    "nerf_last_error": (c_char_p, []),
+    "nerf_stratified_t": (c_int, [c_double, c_double, c_int, _P, _P, _P, _P]),
+    "nerf_sample_positions": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_double, c_double, _P, _P]),
+    "nerf_posenc_fwd": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
+    "nerf_composite_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "nerf_composite_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "nerf_mlp_param_floats": (c_size_t, [c_int]),
+    "nerf_mlp_packed_floats": (c_size_t, [c_int]),
+    "nerf_mlp_fwd_workspace_floats": (c_size_t, [c_int, c_int64]),
+    "nerf_mlp_bwd_workspace_floats": (c_size_t, [c_int, c_int64]),
+    "nerf_mlp_pack": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
+    "nerf_mlp_fwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_double, c_double, _P, _P, _P, _P]),
+    "nerf_mlp_bwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "nerf_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_double, c_double, c_double, c_double, c_double, _P]),
+    "nerf_weights_to_cdf": (c_int, [_P, c_int64, c_int, _P, _P]),
+    "nerf_sample_pdf": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
+}
+EXPORTS = tuple(_SIGS)
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.nerf_abi_version() != ABI_VERSION:
+    raise RuntimeError(f"libnerf_hip.so ABI {lib.nerf_abi_version()} != expected {ABI_VERSION}")
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib.nerf_last_error().decode()}")
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
+    """Device pointer of a tensor after validating what the kernels assume."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; this build runs on a HIP device only (no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], name: str) -> Optional[int]:
+    return None if t is None else _dev(t, name)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------- sampling
+def stratified_t(near: float, far: float, S: int, u: torch.Tensor, want_deltas: bool = True):
+    if u.shape != (S,):
+        raise ValueError(f"u must have shape ({S},), got {tuple(u.shape)}")
+    t = torch.empty_like(u)
+    deltas = torch.empty_like(u) if want_deltas else None
+    _check(lib.nerf_stratified_t(float(near), float(far), S, _dev(u, "u"), _dev(t, "t"), _opt(deltas, "deltas"),
+                                 _stream()), "nerf_stratified_t")
+    return t, deltas
+
+
+def sample_positions(rays_o: torch.Tensor, rays_d: torch.Tensor, t: torch.Tensor, normalize: bool, near: float,
+                     far: float) -> torch.Tensor:
+    R, S = rays_o.shape[0], t.shape[0]
+    if rays_o.shape != (R, 3) or rays_d.shape != (R, 3):
+        raise ValueError("rays_o and rays_d must be [R,3]")
+    pos = torch.empty((R, S, 3), dtype=torch.float32, device=rays_o.device)
+    _check(lib.nerf_sample_positions(_dev(rays_o, "rays_o"), _dev(rays_d, "rays_d"), _dev(t, "t"), R, S,
+                                     int(normalize), float(near), float(far), _dev(pos, "pos"), _stream()),
+           "nerf_sample_positions")
+    return pos
+
+
+def posenc(x: torch.Tensor, L: int) -> torch.Tensor:
+    if x.dim() != 2:
+        raise ValueError("positional_encoding expects [M,D]")
+    M, D = x.shape
+    out = torch.empty((M, D * (1 + 2 * L)), dtype=torch.float32, device=x.device)
+    _check(lib.nerf_posenc_fwd(_dev(x, "x"), M, D, L, _dev(out, "out"), _stream()), "nerf_posenc_fwd")
+    return out
+
+
+# --------------------------------------------------------------------------- compositing
+def composite_fwd(colors, densities, deltas, white: bool, t=None, want_weights=False, want_depth=False,
+                  want_acc=False):
+    R, S = densities.shape
+    if colors.shape != (R, S, 3) or deltas.shape != (S,):
+        raise ValueError(f"composite: colors {tuple(colors.shape)} densities {tuple(densities.shape)} "
+                         f"deltas {tuple(deltas.shape)} do not agree")
+    dev = densities.device
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    weights = torch.empty((R, S), dtype=torch.float32, device=dev) if want_weights else None
+    depth = torch.empty((R,), dtype=torch.float32, device=dev) if want_depth else None
+    acc = torch.empty((R,), dtype=torch.float32, device=dev) if want_acc else None
+    if want_depth and t is None:
+        raise ValueError("depth output needs t")
+    _check(lib.nerf_composite_fwd(_dev(colors, "colors"), _dev(densities, "densities"), _dev(deltas, "deltas"),
+                                  _opt(t, "t"), R, S, int(bool(white)), _dev(rgb, "rgb"), _opt(weights, "weights"),
+                                  _opt(depth, "depth"), _opt(acc, "acc"), _stream()), "nerf_composite_fwd")
+    return rgb, weights, depth, acc
+
+
+def composite_bwd(colors, densities, deltas, white: bool, grad_rgb):
+    R, S = densities.shape
+    dcolors = torch.empty_like(colors)
+    ddens = torch.empty_like(densities)
+    _check(lib.nerf_composite_bwd(_dev(colors, "colors"), _dev(densities, "densities"), _dev(deltas, "deltas"), R, S,
+                                  int(bool(white)), _dev(grad_rgb, "grad_rgb"), _dev(dcolors, "dcolors"),
+                                  _dev(ddens, "ddensities"), _stream()), "nerf_composite_bwd")
+    return dcolors, ddens
+
+
+# --------------------------------------------------------------------------- MLP
+def param_floats(model: int) -> int:
+    return lib.nerf_mlp_param_floats(model)
+
+
+def packed_floats(model: int) -> int:
+    return lib.nerf_mlp_packed_floats(model)
+
+
+def mlp_pack(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if len(params) != NUM_PARAM_TENSORS:
+        raise ValueError(f"expected {NUM_PARAM_TENSORS} parameter tensors, got {len(params)}")
+    dev = params[0].device
+    if out is None:
+        out = torch.empty(packed_floats(model), dtype=torch.float32, device=dev)
+    ptrs = (c_void_p * NUM_PARAM_TENSORS)(*[_dev(p, f"params[{i}]") for i, p in enumerate(params)])
+    _check(lib.nerf_mlp_pack(model, ptrs, _dev(out, "packed"), _stream()), "nerf_mlp_pack")
+    return out
+
+
+def mlp_fwd(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None, rays_o=None, rays_d=None, t=None,
+            S: int = 0, near: float = 0.0, far: float = 1.0, train: bool = False):
+    dev = packed.device
+    colors = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    density = torch.empty((M,), dtype=torch.float32, device=dev)
+    ws = None
+    if train:
+        ws = torch.empty(lib.nerf_mlp_fwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
+    _check(lib.nerf_mlp_fwd(model, _dev(packed, "packed"), M, _opt(points, "points"), _opt(dirs, "dirs"),
+                            _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S, float(near), float(far),
+                            _dev(colors, "colors"), _dev(density, "density"), _opt(ws, "workspace"), _stream()),
+           "nerf_mlp_fwd")
+    return colors, density, ws
+
+
+def mlp_bwd(model: int, packed: torch.Tensor, M: int, dcolors, ddensity, colors, ws, grads: Optional[torch.Tensor] = None):
+    dev = packed.device
+    if grads is None:
+        grads = torch.empty(param_floats(model), dtype=torch.float32, device=dev)
+    bw = torch.empty(lib.nerf_mlp_bwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
+    _check(lib.nerf_mlp_bwd(model, _dev(packed, "packed"), M, _dev(dcolors, "dcolors"), _dev(ddensity, "ddensity"),
+                            _dev(colors, "colors"), _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
+                            _dev(grads, "grads"), _stream()), "nerf_mlp_bwd")
+    return grads
+
+
+def adam_step(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0) -> None:
+    n = p.numel()
+    if not (g.numel() == m.numel() == v.numel() == n):
+        raise ValueError("adam_step: p, g, m, v must have the same number of elements")
+    _check(lib.nerf_adam_step(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), n, step, lr, beta1, beta2, eps,
+                              grad_scale, _stream()), "nerf_adam_step")
+
+
+# --------------------------------------------------------------------------- hierarchical sampling
+def weights_to_cdf(weights: torch.Tensor) -> torch.Tensor:
+    R, B = weights.shape
+    cdf = torch.empty((R, B + 1), dtype=torch.float32, device=weights.device)
+    _check(lib.nerf_weights_to_cdf(_dev(weights, "weights"), R, B, _dev(cdf, "cdf"), _stream()), "nerf_weights_to_cdf")
+    return cdf
+
+
+def sample_pdf(bins: torch.Tensor, cdf: torch.Tensor, u: torch.Tensor):
+    R, B1 = bins.shape
+    if cdf.shape != (R, B1) or u.shape[0] != R:
+        raise ValueError("sample_pdf: bins/cdf must be [R,B+1] and u [R,N]")
+    N = u.shape[1]
+    samples = torch.empty((R, N), dtype=torch.float32, device=bins.device)
+    idx = torch.empty((R, N), dtype=torch.int32, device=bins.device)
+    _check(lib.nerf_sample_pdf(_dev(bins, "bins"), _dev(cdf, "cdf"), _dev(u, "u"), R, B1 - 1, N, _dev(samples, "samples"),
+                               _dev(idx, "idx", torch.int32), _stream()), "nerf_sample_pdf")
+    return samples, idx

@@ -1,0 +1,148 @@
+"""NeRF and Siren modules whose forward/backward run as fused HIP kernels.
+
+Drop-in for the reference's nerf/models.py: same class names, constructor arguments,
+sub-module names (hence identical state_dict keys and shapes, so the reference's
+checkpoints load and torch.optim.Adam sees the same 24 tensors), same
+forward(points, rays_d) -> (colors[M,3], density[M]).  Only the architecture the
+reference's callers build (train.py:101-103, all-default arguments) has a kernel; any
+other size raises instead of silently running something else.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _hip
+from .ops import MLPFunction, PackedWeights, _f32c
+
+
+def _relu_stack(dims: List[int], last_act: bool) -> nn.Sequential:
+    mods: List[nn.Module] = []
+    for i in range(len(dims) - 1):
+        mods.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2 or last_act:
+            mods.append(nn.ReLU())
+    return nn.Sequential(*mods)
+
+
+class _FusedMLP(nn.Module):
+    """Shared plumbing: ordered parameter list, packed-weight cache, kernel dispatch."""
+
+    model_id: int = -1
+
+    def _init_fused(self) -> None:
+        self._packed = PackedWeights(self.model_id)
+
+    def ordered_parameters(self) -> List[torch.Tensor]:
+        """The 24 tensors in state_dict order (the order the C ABI expects)."""
+        ps = list(self.parameters())
+        if len(ps) != _hip.NUM_PARAM_TENSORS:
+            raise RuntimeError(f"expected {_hip.NUM_PARAM_TENSORS} parameter tensors, found {len(ps)}")
+        return ps
+
+    def packed_weights(self) -> torch.Tensor:
+        return self._packed.get(self.ordered_parameters())
+
+    def invalidate_packed(self) -> None:
+        """Call after modifying parameter memory behind autograd's back (fused optimizer)."""
+        self._packed.invalidate()
+
+    def _check_supported(self) -> None:
+        raise NotImplementedError
+
+    def forward(self, points: torch.Tensor, rays_d: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        self._check_supported()
+        if not points.is_cuda:
+            raise RuntimeError("this build has no CPU path: move the model and its inputs to the HIP device "
+                               "(model.to('cuda'))")
+        if points.requires_grad or rays_d.requires_grad:
+            raise NotImplementedError("gradients with respect to points/directions are not provided "
+                                      "(the reference's callers never request them)")
+        if points.dim() != 2 or points.shape[1] != 3 or rays_d.shape != points.shape:
+            raise ValueError("points and rays_d must both be [M,3]")
+        params = self.ordered_parameters()
+        return MLPFunction.apply(self.model_id, self.packed_weights(), _f32c(points), _f32c(rays_d), *params)
+
+
+class NeRF(_FusedMLP):
+    """ReLU MLP with positional encoding (reference nerf/models.py:9-75):
+    block1 63->256 x5, block2 [256+63]->256 x4 ->257 (last column = raw density),
+    rgb_head [256+27]->128->3 with sigmoid."""
+
+    model_id = _hip.MODEL_NERF
+
+    def __init__(self, pos_encoding_dim: int = 10, dir_encoding_dim: int = 4, hidden_dim: int = 256) -> None:
+        super().__init__()
+        pe, de, h = 3 + 6 * pos_encoding_dim, 3 + 6 * dir_encoding_dim, hidden_dim
+        self.block1 = _relu_stack([pe, h, h, h, h, h], last_act=True)
+        self.block2 = _relu_stack([h + pe, h, h, h, h, h + 1], last_act=False)
+        self.rgb_head = nn.Sequential(nn.Linear(h + de, h // 2), nn.ReLU(), nn.Linear(h // 2, 3), nn.Sigmoid())
+        self.pos_encoding_dim, self.dir_encoding_dim, self.hidden_dim = pos_encoding_dim, dir_encoding_dim, hidden_dim
+        self._init_fused()
+
+    def _check_supported(self) -> None:
+        if (self.pos_encoding_dim, self.dir_encoding_dim, self.hidden_dim) != (10, 4, 256):
+            raise NotImplementedError("the HIP kernels cover NeRF(pos_encoding_dim=10, dir_encoding_dim=4, "
+                                      "hidden_dim=256) only")
+
+
+class Sine(nn.Module):
+    """sin(w0 x) (reference nerf/models.py:78-90); kept for state_dict/module-tree parity."""
+
+    def __init__(self, w0: float = 30.0) -> None:
+        super().__init__()
+        self.w0 = w0
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.sin(self.w0 * x)
+
+
+class SirenLayer(nn.Module):
+    """Linear + sine with the SIREN initialisation of the reference (nerf/models.py:117-122):
+    weight AND bias ~ U(+-1/in) for the first layer, U(+-sqrt(6/in)/w0) otherwise."""
+
+    def __init__(self, input_dim: int, hidden_dim: int, w0: float = 1.0, is_first: bool = False) -> None:
+        super().__init__()
+        self.layer = nn.Linear(input_dim, hidden_dim, bias=True)
+        self.activation = Sine(w0)
+        self.is_first, self.input_dim, self.w0, self.c = is_first, input_dim, w0, 6
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        bound = 1.0 / self.input_dim if self.is_first else math.sqrt(self.c / self.input_dim) / self.w0
+        with torch.no_grad():
+            self.layer.weight.uniform_(-bound, bound)
+            self.layer.bias.uniform_(-bound, bound)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.activation(self.layer(x))
+
+
+class Siren(_FusedMLP):
+    """Sine MLP on raw xyz (reference nerf/models.py:130-203): 8 sine layers (w0 30 then 1),
+    density = relu(linear)*sigma_mul, rgb = sigmoid(linear(sine-layer([remap(base), enc(dir)]))*rgb_mul)."""
+
+    model_id = _hip.MODEL_SIREN
+
+    def __init__(self, num_layers: int = 8, hidden_dim: int = 256, dir_encoding_dim: int = 4, sigma_mul: float = 10.,
+                 rgb_mul: float = 1., w0: float = 30., hidden_w0: float = 1.) -> None:
+        super().__init__()
+        self.dir_encoding_dim, self.sigma_mul, self.rgb_mul = dir_encoding_dim, sigma_mul, rgb_mul
+        self._cfg = (num_layers, hidden_dim, dir_encoding_dim, float(sigma_mul), float(rgb_mul), float(w0),
+                     float(hidden_w0))
+        layers = [SirenLayer(3, hidden_dim, w0=w0, is_first=True)]
+        layers += [SirenLayer(hidden_dim, hidden_dim, w0=hidden_w0) for _ in range(num_layers - 1)]
+        self.block1 = nn.Sequential(*layers)
+        self.density_branch = nn.Sequential(nn.Linear(hidden_dim, 1))
+        self.feature_remap = nn.Sequential(nn.Linear(hidden_dim, hidden_dim))
+        self.rgb_head = nn.Sequential(
+            SirenLayer(hidden_dim + 6 * dir_encoding_dim + 3, hidden_dim // 2, w0=hidden_w0),
+            nn.Linear(hidden_dim // 2, 3))
+        self._init_fused()
+
+    def _check_supported(self) -> None:
+        if self._cfg != (8, 256, 4, 10.0, 1.0, 30.0, 1.0):
+            raise NotImplementedError("the HIP kernels cover Siren() with the reference's default arguments only")

@@ -1,0 +1,142 @@
+"""Autograd bridges between PyTorch and the HIP kernels (no arithmetic here)."""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+
+from . import _hip
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """fp32 + contiguous view of a tensor the kernels can take (expand() views and
+    slices with a stride are copied; chunk slices along dim 0 are already contiguous)."""
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class PackedWeights:
+    """Caches the fragment-ordered weight image of one module and re-packs it whenever
+    a parameter was replaced or modified in place (optimizer step, load_state_dict)."""
+
+    def __init__(self, model_id: int):
+        self.model_id = model_id
+        self._key = None
+        self._img = None
+
+    def invalidate(self) -> None:
+        self._key = None
+
+    def get(self, params: Sequence[torch.Tensor]) -> torch.Tensor:
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key != self._key or self._img is None or self._img.device != params[0].device:
+            datas = [_f32c(p.detach()) for p in params]
+            reuse = self._img is not None and self._img.device == params[0].device
+            self._img = _hip.mlp_pack(self.model_id, datas, self._img if reuse else None)
+            self._key = key
+        return self._img
+
+
+def _split_grads(flat: torch.Tensor, params: Sequence[torch.Tensor]):
+    out, off = [], 0
+    for p in params:
+        n = p.numel()
+        out.append(flat[off:off + n].view(p.shape))
+        off += n
+    return out
+
+
+class MLPFunction(torch.autograd.Function):
+    """(colors, density) = model(points, dirs) through the fused encode+MLP kernel;
+    backward yields the 24 parameter gradients (flat buffer, state_dict order)."""
+
+    @staticmethod
+    def forward(ctx, model_id, packed, points, dirs, *params):
+        M = points.shape[0]
+        train = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        colors, density, ws = _hip.mlp_fwd(model_id, packed, M, points=points, dirs=dirs, train=train)
+        ctx.model_id, ctx.M, ctx.train = model_id, M, train
+        ctx.nparams = len(params)
+        if train:
+            ctx.save_for_backward(packed, colors, ws)
+            ctx.shapes = [p.shape for p in params]
+        return colors, density
+
+    @staticmethod
+    def backward(ctx, dcolors, ddensity):
+        if not ctx.train:
+            raise RuntimeError("backward through an inference-mode forward")
+        packed, colors, ws = ctx.saved_tensors
+        if dcolors is None:
+            dcolors = torch.zeros_like(colors)
+        if ddensity is None:
+            ddensity = torch.zeros((ctx.M,), dtype=torch.float32, device=colors.device)
+        flat = _hip.mlp_bwd(ctx.model_id, packed, ctx.M, _f32c(dcolors), _f32c(ddensity), colors, ws)
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for s in shp:
+                n *= s
+            grads.append(flat[off:off + n].view(shp))
+            off += n
+        return (None, None, None, None, *grads)
+
+
+class RenderFunction(torch.autograd.Function):
+    """rgb = composite(model(sample(rays, t))) for one ray chunk: positions are generated
+    inside the MLP kernel, colors/densities go straight to the compositing kernel."""
+
+    @staticmethod
+    def forward(ctx, model_id, packed, rays_o, rays_d, t, deltas, near, far, white, want_extras, *params):
+        R, S = rays_o.shape[0], t.shape[0]
+        M = R * S
+        train = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        colors, density, ws = _hip.mlp_fwd(model_id, packed, M, rays_o=rays_o, rays_d=rays_d, t=t, S=S, near=near,
+                                           far=far, train=train)
+        colors = colors.view(R, S, 3)
+        density = density.view(R, S)
+        rgb, weights, depth, acc = _hip.composite_fwd(colors, density, deltas, white, t=t, want_weights=want_extras,
+                                                      want_depth=want_extras, want_acc=want_extras)
+        ctx.model_id, ctx.M, ctx.train, ctx.white = model_id, M, train, bool(white)
+        if train:
+            ctx.save_for_backward(packed, colors, density, deltas, ws)
+            ctx.shapes = [p.shape for p in params]
+        if want_extras:
+            ctx.mark_non_differentiable(weights, depth, acc)
+            return rgb, weights, depth, acc
+        return rgb
+
+    @staticmethod
+    def backward(ctx, grad_rgb, *unused):
+        if not ctx.train:
+            raise RuntimeError("backward through an inference-mode forward")
+        packed, colors, density, deltas, ws = ctx.saved_tensors
+        dcolors, ddens = _hip.composite_bwd(colors, density, deltas, ctx.white, _f32c(grad_rgb))
+        flat = _hip.mlp_bwd(ctx.model_id, packed, ctx.M, dcolors.view(-1, 3), ddens.view(-1), colors.view(-1, 3), ws)
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for s in shp:
+                n *= s
+            grads.append(flat[off:off + n].view(shp))
+            off += n
+        return (None,) * 10 + tuple(grads)
+
+
+class CompositeFunction(torch.autograd.Function):
+    """composite_volume for arbitrary upstream models (colors/densities carry grad)."""
+
+    @staticmethod
+    def forward(ctx, colors, densities, deltas, white):
+        colors, densities, deltas = _f32c(colors), _f32c(densities), _f32c(deltas)
+        rgb, _, _, _ = _hip.composite_fwd(colors, densities, deltas, white)
+        ctx.save_for_backward(colors, densities, deltas)
+        ctx.white = bool(white)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, grad_rgb):
+        colors, densities, deltas = ctx.saved_tensors
+        dcolors, ddens = _hip.composite_bwd(colors, densities, deltas, ctx.white, _f32c(grad_rgb))
+        return dcolors, ddens, None, None
