@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Benchmark of the NeRF hot path on MI355X: train rays/s (fwd + bwd + optimizer).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic rays already resident in HBM:
+draw u, stratified t, fused sample+encode+MLP forward, compositing, MSE, compositing backward,
+fused MLP data-gradient chain, per-layer weight gradients, (N>1: one RCCL all-reduce of the flat
+gradient bucket), one fused Adam launch, weight re-pack.  Workload = BASELINE.json configs[1]:
+lego-shaped synthetic 800x800 scene, 4096 rays per GPU per step, 256 MLP evaluations per ray
+(the reference's num_samples = 256 single pass, config_lego.txt:15; same FLOPs as 64 coarse +
+64+128 fine), NeRF model, fp32.  Weak scaling: every rank renders its own 4096-ray slice of a
+4096*N batch and shares the uniform draw.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "nerf-pytorch_amd"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# algorithmic FLOPs per MLP evaluation (2 * multiply-accumulates)
+FLOPS = {
+    "nerf": {"fwd": 2 * 658944, "dgrad": 2 * 623232, "wgrad": 2 * 658944},
+    "siren": {"fwd": 2 * 561920, "dgrad": 2 * (561920 - 3 * 256 - 27 * 128), "wgrad": 2 * 561920},
+}
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def make_rays(n_views, H, W, device, seed=42):
+    """Pinhole rays as nerf/data.py:87-112 would compute them for spherical poses
+    (eval.py:36-41), generated on the device with torch ops; targets uniform in [0,1)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    fov = 0.6911112
+    focal = 0.5 * W / np.tan(0.5 * fov)
+    thetas = np.linspace(-180.0, 180.0, n_views + 1)[:-1]
+    u = torch.arange(W, dtype=torch.float32, device=device)
+    v = torch.arange(H, dtype=torch.float32, device=device)
+    vg, ug = torch.meshgrid(v, u, indexing="ij")
+    dirs_cam = torch.stack([ug - 0.5 * W, -(vg - 0.5 * H), -torch.full_like(ug, float(focal))], dim=-1).reshape(-1, 3)
+    ro, rd = [], []
+    for th in thetas:
+        c2w = torch.from_numpy(_pose_spherical(float(th), -30.0, 4.0)).to(device)
+        d = dirs_cam @ c2w[:3, :3].T
+        d = d / d.norm(dim=-1, keepdim=True)
+        rd.append(d)
+        ro.append(c2w[:3, 3].expand_as(d))
+    rays_o = torch.cat(ro).contiguous()
+    rays_d = torch.cat(rd).contiguous()
+    target = torch.rand(rays_o.shape[0], 3, generator=g).to(device)
+    return rays_o, rays_d, target
+
+
+def _pose_spherical(theta, phi, radius):
+    t = np.eye(4, dtype=np.float32); t[2, 3] = radius
+    ph = phi / 180.0 * np.pi
+    rx = np.eye(4, dtype=np.float32); rx[1, 1] = rx[2, 2] = np.cos(ph); rx[1, 2] = -np.sin(ph); rx[2, 1] = np.sin(ph)
+    th = theta / 180.0 * np.pi
+    ry = np.eye(4, dtype=np.float32); ry[0, 0] = ry[2, 2] = np.cos(th); ry[0, 2] = -np.sin(th); ry[2, 0] = np.sin(th)
+    swap = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=np.float32)
+    return (swap @ (ry @ (rx @ t))).astype(np.float32)
+
+
+def cpu_baseline(model_name, rays, samples, steps=2):
+    """The CPU restatement (oracle) timed on the host cores: same step (render, MSE, backward,
+    Adam) on a bounded sample of the same workload."""
+    from oracle import nerf_oracle as O
+    torch.manual_seed(0)
+    is_nerf = model_name == "nerf"
+    shapes = O.nerf_param_shapes() if is_nerf else O.siren_param_shapes()
+    params = O.closed_form_params(shapes, gains=None if is_nerf else O.SIREN_GAINS)
+    for p in params.values():
+        p.requires_grad_(True)
+    fwd = O.nerf_forward if is_nerf else O.siren_forward
+    o = torch.randn(rays, 3); o = 4 * o / o.norm(dim=1, keepdim=True)
+    d = -o / 4 + 0.1 * torch.randn(rays, 3); d = d / d.norm(dim=1, keepdim=True)
+    target = torch.rand(rays, 3)
+    m = {n: torch.zeros_like(p) for n, p in params.items()}
+    v = {n: torch.zeros_like(p) for n, p in params.items()}
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        rgb = O.render(lambda x, dd: fwd(params, x, dd), o, d, 2.0, 6.0, samples, [torch.rand(samples)])
+        loss = torch.nn.functional.mse_loss(rgb, target)
+        grads = torch.autograd.grad(loss, list(params.values()))
+        with torch.no_grad():
+            for (n, p), g in zip(params.items(), grads):
+                O.adam_step(p, g, m[n], v[n], it + 1, 5e-4)
+        times.append(time.perf_counter() - t0)
+    best = float(np.median(times[1:]))
+    return {"value": rays / best, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{rays} rays x {samples} samples, {model_name}, fwd+bwd+Adam, median of {steps} steps after 1 warm-up "
+                      f"(oracle/nerf_oracle.py, torch CPU fp32)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="nerf", choices=["nerf", "siren"])
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    ap.add_argument("--samples", type=int, default=256)
+    ap.add_argument("--views", type=int, default=100)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=1024)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from nerf import _hip, parallel
+    from nerf.models import NeRF, Siren
+    from nerf.rendering import render_nerf
+
+    torch.manual_seed(42)
+    np.random.seed(42)
+    model = (NeRF() if args.model == "nerf" else Siren()).to(dev)
+    flat = parallel.FlatParameters(model)
+    flat.broadcast_parameters(0)
+    opt = parallel.FusedAdam(flat, lr=5e-4)
+    near, far, S, B = 2.0, 6.0, args.samples, args.rays
+
+    # ray pool resident in HBM; ranks own disjoint view ranges of the same scene
+    views_per_rank = max(1, min(args.views // max(world, 1), 12))
+    rays_o, rays_d, target = make_rays(views_per_rank, args.res, args.res, dev, seed=42 + rank)
+    n_pool = rays_o.shape[0]
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    ugen = torch.Generator(device=dev).manual_seed(999)  # same seed on all ranks; also broadcast
+
+    def train_step(step):
+        idx = torch.randint(0, n_pool, (B,), device=dev, generator=gen)
+        o, d, tgt = rays_o[idx], rays_d[idx], target[idx]
+        u = parallel.shared_uniform(S, dev, ugen)
+        pred = render_nerf(model, o, d, near, far, num_samples=S, device=dev, white_background=True,
+                           chunk_size=max(B, 8192), u=[u])
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(pred, tgt)
+        loss.backward()
+        flat.all_reduce_mean()
+        opt.lr = opt.base_lr * parallel.lr_lambda(step, opt.base_lr, 300.0, 0.1, 1e-4)
+        opt.step()
+        return loss
+
+    def infer_step(step):
+        idx = torch.randint(0, n_pool, (B,), device=dev, generator=gen)
+        with torch.no_grad():
+            return render_nerf(model, rays_o[idx], rays_d[idx], near, far, num_samples=S, device=dev,
+                               white_background=True, chunk_size=max(B, 8192))
+
+    step_fn = train_step if args.mode == "train" else infer_step
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step_fn(i)
+    barrier()
+    _hip.timers.enabled = True
+    _hip.timers.reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step_fn(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _hip.timers.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final = float(out.float().mean().item())
+
+    if rank == 0:
+        M = B * S
+        fl = FLOPS[args.model]
+        tm = _hip.timers.summary()
+        kernels = {}
+        if args.mode == "train":
+            specs = [("mlp_fwd_train", fl["fwd"] * M, "fused sample+encode+MLP forward (training, stores activations)"),
+                     ("mlp_bwd_data", fl["dgrad"] * M, "fused data-gradient chain"),
+                     ("mlp_bwd_weights", fl["wgrad"] * M, "per-layer weight-gradient GEMMs + reductions (launch group)")]
+        else:
+            specs = [("mlp_fwd_infer", fl["fwd"] * M, "fused sample+encode+MLP forward (inference)")]
+        for name, flop, desc in specs:
+            if name in tm:
+                n, ms = tm[name]
+                kernels[name] = {"ms": ms, "tflops": flop / ms / 1e9, "flop_per_launch": flop, "what": desc}
+        dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
+        roof = None
+        if dom:
+            ach = kernels[dom]["tflops"]
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "ms_per_launch": kernels[dom]["ms"],
+                    "flop_per_launch": kernels[dom]["flop_per_launch"]}
+        total_flop = sum(k["flop_per_launch"] for k in kernels.values())
+        ms_step = elapsed / args.steps * 1e3
+        res = {
+            "metric": "train rays/sec (fwd+bwd+Adam, 256 MLP samples/ray)" if args.mode == "train"
+                      else "inference rays/sec (256 MLP samples/ray)",
+            "value": world * B * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"lego-shaped synthetic {args.res}x{args.res} scene, {B} rays/GPU/step x {S} samples/ray, "
+                                   f"{args.model} MLP (fp32 MFMA), {args.mode}", "model": args.model,
+                       "rays_per_gpu": B, "global_batch": B * world, "samples_per_ray": S,
+                       "parallelism": f"dp{world} ray-sharded, flat-bucket RCCL all-reduce" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "kernels": kernels,
+            "step_mfma_frac": (total_flop / (ms_step * 1e-3) / 1e12) / PEAK_F32_MFMA_TFLOPS,
+            "final_value": final,
+        }
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train":
+            res["cpu_baseline"] = cpu_baseline(args.model, args.cpu_rays, S)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

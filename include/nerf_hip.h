@@ -112,6 +112,15 @@ int nerf_mlp_bwd(int model, const float* packed, int64_t M, const float* dcolors
                  const float* colors, const float* fwd_workspace, float* bwd_workspace, float* grads,
                  void* stream);
 
+/* The two stages of nerf_mlp_bwd, callable separately (nerf_mlp_bwd = data then weights):
+ *   _data:    fused per-tile data-gradient chain; fills bwd_workspace with every layer's dY;
+ *   _weights: per-layer dW = dY^T X over all samples (MFMA, two-stage deterministic reduce)
+ *             and bias gradients, written into `grads`. */
+int nerf_mlp_bwd_data(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
+                      const float* colors, const float* fwd_workspace, float* bwd_workspace, void* stream);
+int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
+                         void* stream);
+
 /* ---- optimizer: torch.optim.Adam as train.py:123,182 uses it (no weight decay, no amsgrad) --
  * One launch over a flat parameter buffer: p, g, m, v [n].  step is 1-based. */
 int nerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, double lr, double beta1,

@@ -365,32 +365,49 @@ void thin(Ctx& c, const float* P, int ldp, int AW, const float* Q, int ldq, int 
 
 }  // namespace
 
-extern "C" int nerf_mlp_bwd(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
-                            const float* colors, const float* fwd_workspace, float* bwd_workspace, float* grads,
-                            void* stream) {
+static int bwd_check_args(const char* fn, int model, const float* packed, int64_t M, const float* fwd_workspace,
+                          float* bwd_workspace) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "%s: unknown model %d", fn, model);
+    NERF_REQUIRE(M >= 1, "%s: M=%lld < 1", fn, (long long)M);
+    if (!packed || !fwd_workspace || !bwd_workspace) return nerf_fail(NERF_E_NULL, "%s: NULL pointer argument", fn);
+    const size_t Mp = lay::padded_samples(M);
+    NERF_REQUIRE(Mp / lay::TILE < (1ull << 31), "%s: too many samples", fn);
+    return NERF_OK;
+}
+
+extern "C" int nerf_mlp_bwd_data(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
+                                 const float* colors, const float* fwd_workspace, float* bwd_workspace, void* stream) {
     using namespace lay;
-    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "nerf_mlp_bwd: unknown model %d", model);
-    NERF_REQUIRE(M >= 1, "nerf_mlp_bwd: M=%lld < 1", (long long)M);
-    NERF_REQUIRE_PTR(packed);
+    int rc;
+    if ((rc = bwd_check_args("nerf_mlp_bwd_data", model, packed, M, fwd_workspace, bwd_workspace))) return rc;
     NERF_REQUIRE_PTR(dcolors);
     NERF_REQUIRE_PTR(ddensity);
     NERF_REQUIRE_PTR(colors);
-    NERF_REQUIRE_PTR(fwd_workspace);
-    NERF_REQUIRE_PTR(bwd_workspace);
-    NERF_REQUIRE_PTR(grads);
     const size_t Mp = padded_samples(M);
-    const size_t tiles = Mp / TILE;
-    NERF_REQUIRE(tiles < (1ull << 31) && Mp / 32 < (1ull << 31), "nerf_mlp_bwd: too many samples");
+    const unsigned tiles = (unsigned)(Mp / TILE);
+    hipStream_t st = (hipStream_t)stream;
+    BwdArgs a{packed, M, Mp, dcolors, ddensity, colors, fwd_workspace, bwd_workspace};
+    if (model == NERF_MODEL_NERF) {
+        if ((rc = set_lds(nerf_dgrad_kernel, BWD_LDS_BYTES))) return rc;
+        nerf_dgrad_kernel<<<tiles, 256, BWD_LDS_BYTES, st>>>(a);
+    } else {
+        if ((rc = set_lds(siren_dgrad_kernel, BWD_LDS_BYTES))) return rc;
+        siren_dgrad_kernel<<<tiles, 256, BWD_LDS_BYTES, st>>>(a);
+    }
+    return nerf_check_launch("nerf_mlp_bwd_data");
+}
+
+extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
+                                    void* stream) {
+    using namespace lay;
+    int rc;
+    if ((rc = bwd_check_args("nerf_mlp_bwd_weights", model, grads, M, fwd_workspace, bwd_workspace))) return rc;
+    const size_t Mp = padded_samples(M);
     hipStream_t st = (hipStream_t)stream;
     const float* ws = fwd_workspace;
     float* bw = bwd_workspace;
-    BwdArgs a{packed, M, Mp, dcolors, ddensity, colors, ws, bw};
-    int rc;
     if (model == NERF_MODEL_NERF) {
         using namespace lay::nerf;
-        if ((rc = set_lds(nerf_dgrad_kernel, BWD_LDS_BYTES))) return rc;
-        nerf_dgrad_kernel<<<(unsigned)tiles, 256, BWD_LDS_BYTES, st>>>(a);
-        if ((rc = nerf_check_launch("nerf_dgrad"))) return rc;
         Ctx c{st, Mp, bw + BW_PER_SAMPLE * Mp, 0};
         auto W = [&](int layer) { return grads + param_off(2 * layer); };
         auto B = [&](int layer) { return grads + param_off(2 * layer + 1); };
@@ -411,9 +428,6 @@ extern "C" int nerf_mlp_bwd(int model, const float* packed, int64_t M, const flo
         return c.rc;
     } else {
         using namespace lay::siren;
-        if ((rc = set_lds(siren_dgrad_kernel, BWD_LDS_BYTES))) return rc;
-        siren_dgrad_kernel<<<(unsigned)tiles, 256, BWD_LDS_BYTES, st>>>(a);
-        if ((rc = nerf_check_launch("siren_dgrad"))) return rc;
         Ctx c{st, Mp, bw + BW_PER_SAMPLE * Mp, 0};
         auto W = [&](int layer) { return grads + param_off(2 * layer); };
         auto B = [&](int layer) { return grads + param_off(2 * layer + 1); };
@@ -429,6 +443,15 @@ extern "C" int nerf_mlp_bwd(int model, const float* packed, int64_t M, const flo
         thin(c, ws + WS_G * Mp, HH, HH, bw + BW_DZO * Mp, 4, 3, W(11), 1, HH, nullptr, B(11));
         return c.rc;
     }
+}
+
+extern "C" int nerf_mlp_bwd(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
+                            const float* colors, const float* fwd_workspace, float* bwd_workspace, float* grads,
+                            void* stream) {
+    NERF_REQUIRE_PTR(grads);
+    int rc = nerf_mlp_bwd_data(model, packed, M, dcolors, ddensity, colors, fwd_workspace, bwd_workspace, stream);
+    if (rc) return rc;
+    return nerf_mlp_bwd_weights(model, M, fwd_workspace, bwd_workspace, grads, stream);
 }
 
 // =====================================================================================

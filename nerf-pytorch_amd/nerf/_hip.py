@@ -44,6 +44,8 @@ _SIGS = {
     "nerf_mlp_pack": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
     "nerf_mlp_fwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_double, c_double, _P, _P, _P, _P]),
     "nerf_mlp_bwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "nerf_mlp_bwd_data": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P]),
+    "nerf_mlp_bwd_weights": (c_int, [c_int, c_int64, _P, _P, _P, _P]),
     "nerf_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_double, c_double, c_double, c_double, c_double, _P]),
     "nerf_weights_to_cdf": (c_int, [_P, c_int64, c_int, _P, _P]),
     "nerf_sample_pdf": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
@@ -82,6 +84,39 @@ def _opt(t: Optional[torch.Tensor], name: str) -> Optional[int]:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+class KernelTimers:
+    """Optional HIP-event brackets around named launches, recorded on the stream the kernels
+    run on (the current torch stream).  Used by bench.py for per-kernel roofline numbers;
+    disabled (zero cost) by default."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+
+    def start(self, name):
+        if not self.enabled:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        self.events.setdefault(name, []).append((a, b))
+        return b
+
+    @staticmethod
+    def stop(ev):
+        if ev is not None:
+            ev.record()
+
+    def summary(self):
+        """name -> (launch groups, mean ms); call after a device synchronize."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items() if v}
+
+    def reset(self):
+        self.events = {}
+
+
+timers = KernelTimers()
 
 
 # --------------------------------------------------------------------------- sampling
@@ -174,10 +209,12 @@ def mlp_fwd(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None,
     ws = None
     if train:
         ws = torch.empty(lib.nerf_mlp_fwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
+    ev = timers.start("mlp_fwd_train" if train else "mlp_fwd_infer")
     _check(lib.nerf_mlp_fwd(model, _dev(packed, "packed"), M, _opt(points, "points"), _opt(dirs, "dirs"),
                             _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S, float(near), float(far),
                             _dev(colors, "colors"), _dev(density, "density"), _opt(ws, "workspace"), _stream()),
            "nerf_mlp_fwd")
+    timers.stop(ev)
     return colors, density, ws
 
 
@@ -186,9 +223,15 @@ def mlp_bwd(model: int, packed: torch.Tensor, M: int, dcolors, ddensity, colors,
     if grads is None:
         grads = torch.empty(param_floats(model), dtype=torch.float32, device=dev)
     bw = torch.empty(lib.nerf_mlp_bwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
-    _check(lib.nerf_mlp_bwd(model, _dev(packed, "packed"), M, _dev(dcolors, "dcolors"), _dev(ddensity, "ddensity"),
-                            _dev(colors, "colors"), _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
-                            _dev(grads, "grads"), _stream()), "nerf_mlp_bwd")
+    ev = timers.start("mlp_bwd_data")
+    _check(lib.nerf_mlp_bwd_data(model, _dev(packed, "packed"), M, _dev(dcolors, "dcolors"), _dev(ddensity, "ddensity"),
+                                 _dev(colors, "colors"), _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
+                                 _stream()), "nerf_mlp_bwd_data")
+    timers.stop(ev)
+    ev = timers.start("mlp_bwd_weights")
+    _check(lib.nerf_mlp_bwd_weights(model, M, _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
+                                    _dev(grads, "grads"), _stream()), "nerf_mlp_bwd_weights")
+    timers.stop(ev)
     return grads
 
 

@@ -54,7 +54,7 @@ class MLPFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model_id, packed, points, dirs, *params):
         M = points.shape[0]
-        train = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        train = any(ctx.needs_input_grad[4:])  # all False under no_grad or with frozen parameters
         colors, density, ws = _hip.mlp_fwd(model_id, packed, M, points=points, dirs=dirs, train=train)
         ctx.model_id, ctx.M, ctx.train = model_id, M, train
         ctx.nparams = len(params)
@@ -91,7 +91,7 @@ class RenderFunction(torch.autograd.Function):
     def forward(ctx, model_id, packed, rays_o, rays_d, t, deltas, near, far, white, want_extras, *params):
         R, S = rays_o.shape[0], t.shape[0]
         M = R * S
-        train = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        train = any(ctx.needs_input_grad[10:])  # all False under no_grad or with frozen parameters
         colors, density, ws = _hip.mlp_fwd(model_id, packed, M, rays_o=rays_o, rays_d=rays_d, t=t, S=S, near=near,
                                            far=far, train=train)
         colors = colors.view(R, S, 3)
