@@ -38,3 +38,23 @@ static inline int nerf_check_launch(const char* what) {
 }
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Individually rounded fp32 operations.  HIP's __fadd_rn/__fmul_rn/... are plain operators
+// defined in a header compiled with -ffp-contract=fast, so a mul feeding an add still fuses
+// into an FMA; these helpers carry no contraction permission and survive inlining.
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float div_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a / b;
+}

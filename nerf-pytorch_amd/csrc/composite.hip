@@ -85,9 +85,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_fwd_kernel(
     float prod = 1.0f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-        const float ex = expf(__fmul_rn(-sig[e], dl[e]));
-        alpha[e] = __fsub_rn(1.0f, ex);
-        beta[e] = __fsub_rn(1.0f, alpha[e]);  // 1-(1-e), as the reference computes it
+        const float ex = expf(mul_rn(-sig[e], dl[e]));
+        alpha[e] = sub_rn(1.0f, ex);
+        beta[e] = sub_rn(1.0f, alpha[e]);  // 1-(1-e), as the reference computes it
         prod *= beta[e];
     }
     float T = wave_excl_prod(prod, lane);
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_bwd_kernel(
     float prod = 1.0f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-        ex[e] = expf(__fmul_rn(-sig[e], dl[e]));
-        alpha[e] = __fsub_rn(1.0f, ex[e]);
-        beta[e] = __fsub_rn(1.0f, alpha[e]);
+        ex[e] = expf(mul_rn(-sig[e], dl[e]));
+        alpha[e] = sub_rn(1.0f, ex[e]);
+        beta[e] = sub_rn(1.0f, alpha[e]);
         prod *= beta[e];
     }
     float T = wave_excl_prod(prod, lane);

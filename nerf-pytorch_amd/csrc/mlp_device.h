@@ -145,7 +145,7 @@ __device__ __forceinline__ void encode_axis(float* dst, int axis, float x) {
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         float s, c;
-        nerf_sincosf(__fmul_rn((float)(1 << j), x), &s, &c);
+        nerf_sincosf(mul_rn((float)(1 << j), x), &s, &c);
         dst[3 + 6 * j + axis] = s;
         dst[3 + 6 * j + 3 + axis] = c;
     }

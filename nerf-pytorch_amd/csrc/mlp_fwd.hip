@@ -160,11 +160,13 @@ constexpr int XIN_FLOATS = lay::TILE * 8;
 constexpr int FWD_LDS_BYTES = (ACT_FLOATS + XIN_FLOATS + lay::TILE) * 4;
 
 __device__ __forceinline__ float norm_coord(float p, float nearf, float spanf) {
-    return __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(p, nearf)), spanf), 1.0f);
+#pragma clang fp contract(off)  // each operation rounded on its own, as the reference's tensor ops are
+    return sub_rn(div_rn(mul_rn(2.0f, sub_rn(p, nearf)), spanf), 1.0f);
 }
 
 // xin[s][0..2] = normalised position, xin[s][3..5] = direction (zeros beyond M)
 __device__ __forceinline__ void load_inputs(const FwdArgs& a, size_t m0, float* xin, int tid) {
+#pragma clang fp contract(off)  // o + t*d must not become an FMA (bit-exact positions)
     if (tid < lay::TILE) {
         const size_t m = m0 + tid;
         float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
@@ -178,7 +180,7 @@ __device__ __forceinline__ void load_inputs(const FwdArgs& a, size_t m0, float* 
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     d[c] = a.rays_d[r * 3 + c];
-                    x[c] = norm_coord(__fadd_rn(a.rays_o[r * 3 + c], __fmul_rn(ts, d[c])), a.nearf, a.spanf);
+                    x[c] = norm_coord(add_rn(a.rays_o[r * 3 + c], mul_rn(ts, d[c])), a.nearf, a.spanf);
                 }
             }
         }
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
         for (int s = 0; s < TILE; ++s) {
             const float z = fmaf(xin[s * 8 + 2], w2, fmaf(xin[s * 8 + 1], w1, fmaf(xin[s * 8], w0, b)));
             float sn, cs;
-            nerf_sincosf(__fmul_rn(30.0f, z), &sn, &cs);
+            nerf_sincosf(mul_rn(30.0f, z), &sn, &cs);
             act[s * LDA + tid] = sn;
             if constexpr (TRAIN) {
                 gh[(size_t)s * H + tid] = sn;

@@ -5,6 +5,11 @@
 #include "common.h"
 #include "sincos.h"
 
+// HIP's __fadd_rn/__fmul_rn/__fsub_rn are plain operators, which hipcc's default
+// -ffp-contract=fast would fuse into FMAs; the bit-exact sampling below needs every
+// operation rounded on its own, so contraction is off for this whole file.
+#pragma clang fp contract(off)
+
 thread_local char g_nerf_err[256] = "";
 
 extern "C" int nerf_abi_version(void) { return NERF_ABI_VERSION; }
@@ -22,7 +27,7 @@ __device__ __forceinline__ float strat_t(float lo_end, float hi_end, float step,
     const float lo = linspace_edge(lo_end, hi_end, step, s, S + 1);
     const float hi = linspace_edge(lo_end, hi_end, step, s + 1, S + 1);
     // lower + (upper - lower) * u with separately rounded mul and add (rendering.py:27)
-    return __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), u));
+    return add_rn(lo, mul_rn(sub_rn(hi, lo), u));
 }
 
 __global__ void stratified_t_kernel(float lo_end, float hi_end, float step, int S, const float* __restrict__ u,
@@ -34,7 +39,7 @@ __global__ void stratified_t_kernel(float lo_end, float hi_end, float step, int 
     if (deltas) {
         if (s + 1 < S) {
             const float tn = strat_t(lo_end, hi_end, step, s + 1, S, u[s + 1]);
-            deltas[s] = __fsub_rn(tn, ts);
+            deltas[s] = sub_rn(tn, ts);
         } else {
             deltas[s] = 1e10f;
         }
@@ -57,7 +62,7 @@ extern "C" int nerf_stratified_t(double near, double far, int S, const float* u,
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float normalize_coord(float p, float nearf, float spanf) {
     // 2*(p-near)/(far-near)-1: sub, mul by 2, true division, sub 1 (rendering.py:82)
-    return __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(p, nearf)), spanf), 1.0f);
+    return sub_rn(div_rn(mul_rn(2.0f, sub_rn(p, nearf)), spanf), 1.0f);
 }
 
 __global__ void sample_positions_kernel(const float* __restrict__ o, const float* __restrict__ d,
@@ -70,7 +75,7 @@ __global__ void sample_positions_kernel(const float* __restrict__ o, const float
     const float ts = t[s];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float p = __fadd_rn(o[r * 3 + c], __fmul_rn(ts, d[r * 3 + c]));
+        float p = add_rn(o[r * 3 + c], mul_rn(ts, d[r * 3 + c]));
         if (normalize) p = normalize_coord(p, nearf, spanf);
         pos[m * 3 + c] = p;
     }
@@ -108,7 +113,7 @@ __global__ void posenc_kernel(const float* __restrict__ x, int64_t M, int D, int
     if (j == 0) {
         row[c] = v;
     } else {
-        const float a = __fmul_rn((float)(1u << (j - 1)), v);
+        const float a = mul_rn((float)(1u << (j - 1)), v);
         float sn, cs;
         nerf_sincosf(a, &sn, &cs);
         row[D + 2 * D * (j - 1) + c] = sn;
@@ -191,10 +196,10 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
     }
     const int below = max(lo - 1, 0), above = min(lo, B);
     const float c0 = c[below], c1 = c[above];
-    float den = __fsub_rn(c1, c0);
+    float den = sub_rn(c1, c0);
     if (den < 1e-5f) den = 1.f;
-    const float tt = __fdiv_rn(__fsub_rn(uu, c0), den);
-    samples[e] = __fadd_rn(bn[below], __fmul_rn(tt, __fsub_rn(bn[above], bn[below])));
+    const float tt = div_rn(sub_rn(uu, c0), den);
+    samples[e] = add_rn(bn[below], mul_rn(tt, sub_rn(bn[above], bn[below])));
     idx_out[e] = lo;
 }
 

@@ -201,17 +201,21 @@ def nerf_forward(p: Params, points: Tensor, dirs: Tensor, pos_L: int = 10, dir_L
     acts = {"pe": pe, "de": de}
     h = pe
     for i in range(5):
-        h = torch.relu(_lin(h, p, f"block1.{2*i}"))
-        acts[f"h{i}"] = h
+        z = _lin(h, p, f"block1.{2*i}")
+        h = torch.relu(z)
+        acts[f"z{i}"], acts[f"h{i}"] = z, h
     h = torch.cat([h, pe], dim=1)
     for i in range(4):
-        h = torch.relu(_lin(h, p, f"block2.{2*i}"))
-        acts[f"h{5+i}"] = h
+        z = _lin(h, p, f"block2.{2*i}")
+        h = torch.relu(z)
+        acts[f"z{5+i}"], acts[f"h{5+i}"] = z, h
     f = _lin(h, p, "block2.8")
     acts["f"] = f
+    acts["z_sigma"] = f[:, -1:]
     density = torch.relu(f[:, -1])
-    g = torch.relu(_lin(torch.cat([f[:, :-1], de], dim=1), p, "rgb_head.0"))
-    acts["g"] = g
+    zg = _lin(torch.cat([f[:, :-1], de], dim=1), p, "rgb_head.0")
+    g = torch.relu(zg)
+    acts["z_g"], acts["g"] = zg, g
     colors = torch.sigmoid(_lin(g, p, "rgb_head.2"))
     if return_acts:
         return colors, density, acts
@@ -230,6 +234,7 @@ def siren_forward(p: Params, points: Tensor, dirs: Tensor, num_layers: int = 8, 
         h = torch.sin(w * _lin(h, p, f"block1.{i}.layer"))
         acts[f"h{i}"] = h
     sigma = _lin(h, p, "density_branch.0")
+    acts["z_sigma"] = sigma
     density = (torch.relu(sigma) * sigma_mul).squeeze(-1)
     feat = _lin(h, p, "feature_remap.0")
     acts["f"] = feat
@@ -241,6 +246,15 @@ def siren_forward(p: Params, points: Tensor, dirs: Tensor, num_layers: int = 8, 
     if return_acts:
         return colors, density, acts
     return colors, density
+
+
+def relu_kink_distance(acts) -> Tensor:
+    """Per sample, the smallest |pre-activation| over every ReLU input ("z*" entries of the
+    activations dict).  A sample whose value is within fp32 rounding of zero has an
+    implementation-dependent ReLU decision, hence an implementation-dependent gradient: tests
+    that compare gradients element for element drop such samples."""
+    zs = [v.detach().abs().min(dim=1).values for k, v in acts.items() if k.startswith("z")]
+    return torch.stack(zs, dim=0).min(dim=0).values
 
 
 # ----------------------------------------------------------------------------

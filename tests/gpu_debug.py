@@ -14,7 +14,7 @@ def rel(a, b):
     a = a.detach().cpu().double(); b = b.detach().cpu().double()
     return float((a - b).norm() / (b.norm() + 1e-30)), float((a - b).abs().max())
 
-def run(tag, M=200):
+def run(tag, M=int(os.environ.get("DBG_M", "200"))):
     is_nerf = tag == "nerf"
     shapes = O.nerf_param_shapes() if is_nerf else O.siren_param_shapes()
     params = O.closed_form_params(shapes, gains=None if is_nerf else O.SIREN_GAINS)

@@ -1,0 +1,442 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors the reference produced.  Tolerances (fp32): bit-exact for sampling/positions; 2.5e-7
+absolute for sin/cos; 1e-5 relative (norm-wise per tensor) for rendered values and gradients,
+as the task states."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T = torch.from_numpy
+RTOL = 1e-5
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().reshape(-1)
+    b = (b.detach().cpu() if isinstance(b, torch.Tensor) else T(np.asarray(b))).double().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from nerf import _hip
+    return _hip
+
+
+def make_model(tag):
+    from nerf.models import NeRF, Siren
+    if tag == "nerf":
+        params = O.closed_form_params(O.nerf_param_shapes())
+        m = NeRF()
+    else:
+        params = O.closed_form_params(O.siren_param_shapes(), gains=O.SIREN_GAINS)
+        m = Siren()
+    m.load_state_dict(params)
+    return m.to(DEV), params
+
+
+def oracle_fwd(tag):
+    return O.nerf_forward if tag == "nerf" else O.siren_forward
+
+
+def rays(R, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(R, 3, generator=g)
+    o = 4 * o / o.norm(dim=1, keepdim=True)
+    d = -o / 4 + 0.15 * torch.randn(R, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    return o.contiguous(), d.contiguous()
+
+
+# ----------------------------------------------------------------------------- sampling
+def test_stratified_golden_bit_exact(hip, golden):
+    z = golden("g1_stratified.npz")
+    for ci in range(7):
+        near, far, S, _ = z[f"c{ci}_cfg"]
+        t, deltas = hip.stratified_t(float(near), float(far), int(S), T(z[f"c{ci}_u"]).to(DEV))
+        assert np.array_equal(t.cpu().numpy(), z[f"c{ci}_t"]), ci
+        ref_d = O.sample_deltas(T(z[f"c{ci}_t"])).numpy()
+        assert np.array_equal(deltas.cpu().numpy(), ref_d), ci
+
+
+def test_stratified_sweep_bit_exact(hip):
+    g = torch.Generator().manual_seed(3)
+    for near, far, S in [(2.0, 6.0, 256), (0.05, 3.7, 333), (1e-3, 1e3, 1000), (5.5, 5.75, 17), (2.0, 6.0, 1),
+                         (0.3, 11.1, 64), (2.0, 6.0, 4096)]:
+        u = torch.rand(S, generator=g)
+        t, _ = hip.stratified_t(near, far, S, u.to(DEV))
+        assert np.array_equal(t.cpu().numpy(), O.stratified_t(near, far, S, u).numpy()), (near, far, S)
+
+
+def test_stratified_sampling_consumes_rng_like_reference():
+    from nerf.rendering import stratified_sampling
+    torch.manual_seed(7)
+    u = torch.rand(64, device=DEV)
+    torch.manual_seed(7)
+    t = stratified_sampling(2.0, 6.0, 64, DEV)
+    assert np.array_equal(t.cpu().numpy(), O.stratified_t(2.0, 6.0, 64, u.cpu()).numpy())
+
+
+def test_positions_golden_bit_exact(hip, golden):
+    from nerf.rendering import generate_sample_positions
+    z = golden("g2_positions.npz")
+    o, d = T(z["o"]).to(DEV), T(z["d"]).to(DEV)
+    for S in (64, 256):
+        u = T(z[f"S{S}_u"]).to(DEV)
+        pos, deltas = generate_sample_positions(o, d, 2.0, 6.0, S, DEV, u=u)
+        assert np.array_equal(pos.cpu().numpy(), z[f"S{S}_pos"])
+        assert np.array_equal(deltas.cpu().numpy(), z[f"S{S}_deltas"])
+        t, _ = hip.stratified_t(2.0, 6.0, S, u)
+        posn = hip.sample_positions(o, d, t, True, 2.0, 6.0)
+        assert np.array_equal(posn.cpu().numpy(), z[f"S{S}_posn"])
+
+
+def test_positions_non_dyadic_bounds_bit_exact(hip):
+    o, d = rays(37, 4)
+    g = torch.Generator().manual_seed(9)
+    near, far, S = 0.7, 5.3, 50
+    u = torch.rand(S, generator=g)
+    t_ref = O.stratified_t(near, far, S, u)
+    ref = O.normalize_positions(O.sample_positions(o, d, t_ref), near, far)
+    t, _ = hip.stratified_t(near, far, S, u.to(DEV))
+    got = hip.sample_positions(o.to(DEV), d.to(DEV), t, True, near, far)
+    assert np.array_equal(got.cpu().numpy(), ref.numpy())
+
+
+# ----------------------------------------------------------------------------- encoding
+def test_posenc_golden(golden):
+    from nerf.encoding import positional_encoding
+    z = golden("g3_posenc.npz")
+    x = T(z["x"]).to(DEV)
+    for L, key in ((4, "L4"), (10, "L10")):
+        out = positional_encoding(x, L).cpu().numpy()
+        assert out.shape == z[key].shape
+        assert np.abs(out - z[key]).max() <= 2.5e-7
+        assert np.array_equal(out[:, :3], z["x"])
+
+
+def test_posenc_shapes_and_empty():
+    from nerf.encoding import positional_encoding
+    assert positional_encoding(torch.zeros(0, 3, device=DEV), 10).shape == (0, 63)
+    x = torch.rand(1000, 2, device=DEV) * 4 - 2
+    out = positional_encoding(x, 3)
+    ref = O.positional_encoding(x.cpu(), 3)
+    assert out.shape == ref.shape and (out.cpu() - ref).abs().max() <= 2.5e-7
+
+
+# ----------------------------------------------------------------------------- compositing
+@pytest.mark.parametrize("wb", [True, False])
+def test_composite_golden(hip, golden, wb):
+    from nerf.rendering import composite_volume
+    z = golden("g5_composite.npz")
+    c = T(z["colors"]).to(DEV).requires_grad_(True)
+    s = T(z["densities"]).to(DEV).requires_grad_(True)
+    deltas = T(z["deltas"]).to(DEV)
+    rgb = composite_volume(c, s, deltas, wb)
+    assert rel(rgb, z[f"wb{int(wb)}_rgb"]) < RTOL
+    (rgb * T(z["grad_rgb"]).to(DEV)).sum().backward()
+    assert rel(c.grad, z[f"wb{int(wb)}_dcolors"]) < RTOL
+    assert rel(s.grad, z[f"wb{int(wb)}_ddens"]) < RTOL
+    # edge rows individually: empty ray, beta == 0 mid-ray, nearly transparent, saturated
+    for row in range(4):
+        assert rel(s.grad[row], z[f"wb{int(wb)}_ddens"][row]) < 1e-4 or np.abs(z[f"wb{int(wb)}_ddens"][row]).max() == 0
+        assert torch.isfinite(s.grad[row]).all()
+    _, w, _, acc = hip.composite_fwd(c.detach(), s.detach(), deltas, wb, t=T(z["t"]).to(DEV), want_weights=True,
+                                     want_depth=True, want_acc=True)
+    assert rel(w, z["weights"]) < RTOL
+    assert rel(acc, z["weights"].sum(1)) < RTOL
+
+
+@pytest.mark.parametrize("S", [1, 7, 64, 100, 192, 256, 512, 1000])
+def test_composite_random_sizes(hip, S):
+    g = torch.Generator().manual_seed(S)
+    R = 301
+    dens = torch.relu(torch.randn(R, S, generator=g)) * 10
+    cols = torch.rand(R, S, 3, generator=g)
+    t = O.stratified_t(2.0, 6.0, S, torch.rand(S, generator=g))
+    deltas = O.sample_deltas(t)
+    gr = torch.randn(R, 3, generator=g)
+    c = cols.clone().requires_grad_(True)
+    s = dens.clone().requires_grad_(True)
+    ref = O.composite(c, s, deltas, True)
+    (ref * gr).sum().backward()
+    rgb, w, depth, acc = hip.composite_fwd(cols.to(DEV), dens.to(DEV), deltas.to(DEV), True, t=t.to(DEV),
+                                           want_weights=True, want_depth=True, want_acc=True)
+    dc, ds = hip.composite_bwd(cols.to(DEV), dens.to(DEV), deltas.to(DEV), True, gr.to(DEV))
+    wref, _ = O.composite_weights(dens, deltas)
+    assert rel(rgb, ref) < RTOL and rel(w, wref) < RTOL
+    assert rel(depth, O.composite_depth(wref, t)) < RTOL      # depth: parity unpinned by the reference
+    assert rel(dc, c.grad) < RTOL and rel(ds, s.grad) < RTOL
+
+
+def test_composite_empty(hip):
+    rgb, _, _, _ = hip.composite_fwd(torch.zeros(0, 8, 3, device=DEV), torch.zeros(0, 8, device=DEV),
+                                     torch.ones(8, device=DEV), True)
+    assert rgb.shape == (0, 3)
+
+
+# ----------------------------------------------------------------------------- models
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
+def test_model_golden_forward_backward(golden, tag):
+    z = golden(f"g4_{tag}.npz")
+    model, _ = make_model(tag)
+    colors, dens = model(T(z["pts"]).to(DEV), T(z["dirs"]).to(DEV))
+    assert colors.shape == (96, 3) and dens.shape == (96,)
+    assert rel(colors, z["colors"]) < RTOL and rel(dens, z["density"]) < RTOL
+    ((colors * T(z["gc"]).to(DEV)).sum() + (dens * T(z["gd"]).to(DEV)).sum()).backward()
+    for n, p in model.named_parameters():
+        gn = float(z["gnorm." + n])
+        assert abs(float(p.grad.norm()) - gn) <= 2 * RTOL * gn, n
+        f = p.grad.reshape(-1)
+        step = max(1, f.numel() // 97)
+        sub = f[::step][:97].cpu().numpy()
+        assert np.abs(sub - z["gsub." + n]).max() <= 50 * RTOL * gn / math.sqrt(f.numel()) + 1e-9, n
+
+
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
+@pytest.mark.parametrize("M", [1, 63, 65, 200, 1000])
+def test_model_ragged_sizes_full_gradients(tag, M):
+    """Every gradient tensor, element for element, against autograd of the oracle."""
+    model, params = make_model(tag)
+    g = torch.Generator().manual_seed(M)
+    pts = torch.rand(M, 3, generator=g) * 2 - 1
+    dirs = torch.randn(M, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    gc, gd = torch.randn(M, 3, generator=g), torch.randn(M, generator=g) * 0.1
+    # a ReLU input within rounding of zero makes the gradient implementation-dependent
+    # (any two fp32 matmuls disagree there): drop those samples, about 1 in 1000
+    with torch.no_grad():
+        _, _, acts = oracle_fwd(tag)(params, pts, dirs, return_acts=True)
+    keep = O.relu_kink_distance(acts) > 3e-6
+    assert int(keep.sum()) >= max(1, int(0.95 * M))
+    pts, dirs, gc, gd = pts[keep].contiguous(), dirs[keep].contiguous(), gc[keep].contiguous(), gd[keep].contiguous()
+    for p in params.values():
+        p.requires_grad_(True)
+    c_ref, d_ref = oracle_fwd(tag)(params, pts, dirs)
+    ((c_ref * gc).sum() + (d_ref * gd).sum()).backward()
+    colors, dens = model(pts.to(DEV), dirs.to(DEV))
+    ((colors * gc.to(DEV)).sum() + (dens * gd.to(DEV)).sum()).backward()
+    assert rel(colors, c_ref) < RTOL and rel(dens, d_ref) < RTOL
+    for (n, p), pr in zip(model.named_parameters(), params.values()):
+        assert rel(p.grad, pr.grad) < RTOL, (n, rel(p.grad, pr.grad))
+
+
+def test_model_empty_and_no_grad():
+    model, _ = make_model("nerf")
+    c, d = model(torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV))
+    assert c.shape == (0, 3) and d.shape == (0,)
+    with torch.no_grad():
+        c, d = model(torch.zeros(5, 3, device=DEV), torch.ones(5, 3, device=DEV))
+    assert not c.requires_grad
+
+
+def test_repack_after_parameter_update():
+    model, params = make_model("nerf")
+    x, d = torch.rand(64, 3, device=DEV), torch.rand(64, 3, device=DEV)
+    with torch.no_grad():
+        a, _ = model(x, d)
+        model.rgb_head[2].bias.add_(0.5)
+        b, _ = model(x, d)
+        params["rgb_head.2.bias"] = params["rgb_head.2.bias"] + 0.5
+    ref, _ = O.nerf_forward(params, x.cpu(), d.cpu())
+    assert not torch.equal(a, b) and rel(b, ref) < RTOL
+
+
+# ----------------------------------------------------------------------------- renderer
+@pytest.mark.parametrize("tag", ["nerf_S64_onechunk", "nerf_S256_chunk24", "nerf_S64_black",
+                                 "siren_S64_onechunk", "siren_S256_chunk24"])
+def test_render_golden(golden, tag):
+    from nerf.rendering import render_nerf
+    z = golden(f"g6_{tag}.npz")
+    R, S, chunk, _, wb = (int(v) for v in z["cfg"])
+    model, _ = make_model(tag.split("_")[0])
+    us = [T(u).to(DEV) for u in z["us"]]
+    rgb = render_nerf(model, T(z["o"]), T(z["d"]), 2.0, 6.0, num_samples=S, device=DEV, white_background=bool(wb),
+                      chunk_size=chunk, u=us)
+    assert rgb.shape == (R, 3) and rel(rgb, z["rgb"]) < RTOL
+    loss = torch.nn.functional.mse_loss(rgb, T(z["target"]).to(DEV))
+    assert abs(float(loss.detach()) - float(z["loss"])) <= RTOL * float(z["loss"])
+    loss.backward()
+    for n, p in model.named_parameters():
+        gn = float(z["gnorm." + n])
+        assert abs(float(p.grad.norm()) - gn) <= 3 * RTOL * gn, (n, float(p.grad.norm()), gn)
+
+
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
+def test_render_ragged_vs_oracle(tag):
+    """S = 192 (tiles straddle rays), R not a multiple of the chunk, extras returned."""
+    from nerf.rendering import render_nerf
+    model, params = make_model(tag)
+    R, S, chunk = 150, 192, 64
+    o, d = rays(R, 11)
+    g = torch.Generator().manual_seed(12)
+    us = [torch.rand(S, generator=g) for _ in range(3)]
+    fwd = oracle_fwd(tag)
+    ref, wref, dref = O.render(lambda x, v: fwd(params, x, v), o, d, 2.0, 6.0, S, us, chunk_size=chunk,
+                               return_extras=True)
+    with torch.no_grad():
+        rgb, w, depth, acc = render_nerf(model, o, d, 2.0, 6.0, num_samples=S, device=DEV, chunk_size=chunk,
+                                         u=[u.to(DEV) for u in us], return_extras=True)
+    assert rel(rgb, ref) < RTOL and rel(w, wref) < 2 * RTOL and rel(depth, dref) < 2 * RTOL
+    assert rel(acc, wref.sum(1)) < RTOL
+
+
+def test_render_generic_module_path():
+    """A model that is not one of this package's fused modules goes through sample -> forward ->
+    composite with autograd through the module (reference rendering.py:195-223)."""
+    from nerf.rendering import render_nerf
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(6, 4)
+
+        def forward(self, p, d):
+            y = self.lin(torch.cat([p, d], dim=1))
+            return torch.sigmoid(y[:, :3]), torch.relu(y[:, 3]) * 3
+
+    torch.manual_seed(0)
+    toy = Toy()
+    o, d = rays(40, 21)
+    u = torch.rand(32)
+    ref = O.render(lambda x, v: toy(x, v), o, d, 2.0, 6.0, 32, [u])
+    gref = torch.autograd.grad(ref.square().sum(), list(toy.parameters()))
+    toy_g = Toy().to(DEV)
+    toy_g.load_state_dict(toy.state_dict())
+    rgb = render_nerf(toy_g, o, d, 2.0, 6.0, num_samples=32, device=DEV, u=[u.to(DEV)])
+    assert rel(rgb, ref) < RTOL
+    g = torch.autograd.grad(rgb.square().sum(), list(toy_g.parameters()))
+    for a, b in zip(g, gref):
+        assert rel(a, b) < 5 * RTOL
+
+
+# ----------------------------------------------------------------------------- training step
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
+@pytest.mark.parametrize("optim", ["torch", "fused"])
+def test_adam_trajectory_golden(golden, tag, optim):
+    """Five optimizer steps as train.py:166-183 runs them; torch.optim.Adam + LambdaLR on the
+    drop-in modules, and the fused flat Adam kernel.  Tolerance on the loss: 1e-5 relative at
+    step 0 (no update yet), 1e-4 after one update, 2e-3 later: Adam's g/sqrt(v) turns last-bit
+    differences of near-zero gradient entries into O(lr) parameter steps, and at lr 5e-4 these
+    five steps are far from converged (the loss moves by 2x per step), so the difference grows
+    geometrically.  A wrong bias correction, schedule or update rule is off by >1e-2."""
+    from nerf import parallel
+    from nerf.rendering import render_nerf
+    z = golden(f"g7_{tag}.npz")
+    R, S, steps = (int(v) for v in z["cfg"])
+    model, _ = make_model(tag)
+    o, d, tgt = T(z["o"]).to(DEV), T(z["d"]).to(DEV), T(z["target"]).to(DEV)
+    lr = 5e-4
+    if optim == "torch":
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
+        gamma = 0.1 ** (1 / (300.0 * 1000))
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: max(gamma ** s, 1e-4 / lr))
+    else:
+        flat = parallel.FlatParameters(model)
+        opt = parallel.FusedAdam(flat, lr=lr)
+    for it in range(steps):
+        pred = render_nerf(model, o, d, 2.0, 6.0, num_samples=S, device=DEV, white_background=True, chunk_size=8192,
+                           u=[T(z["us"][it]).to(DEV)])
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(pred, tgt)
+        loss.backward()
+        if optim == "fused":
+            opt.lr = lr * parallel.lr_lambda(it, lr, 300.0, 0.1, 1e-4)
+        opt.step()
+        if optim == "torch":
+            sched.step()
+        tol = (1e-5, 1e-4, 2e-3, 2e-3, 2e-3)[it]
+        assert abs(float(loss.detach()) - z["losses"][it]) <= tol * z["losses"][it], (it, float(loss.detach()))
+    for n, p in model.named_parameters():
+        assert abs(float(p.detach().norm()) - float(z["pnorm." + n])) <= 1e-3 * float(z["pnorm." + n]) + 1e-7, n
+
+
+def test_fused_adam_matches_torch_adam(hip):
+    torch.manual_seed(0)
+    n = 100003
+    p0, g0 = torch.randn(n, device=DEV), torch.randn(n, device=DEV) * 1e-3
+    p = p0.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=5e-4)
+    for step in range(1, 4):
+        g = g0 * step
+        hip.adam_step(p, g, m, v, step, 5e-4)
+        pr.grad = g.clone()
+        opt.step()
+    assert rel(p, pr) < 1e-6 and (p - pr.detach()).abs().max() < 1e-6
+
+
+# ----------------------------------------------------------------------------- full-size properties
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
+def test_full_size_properties(hip, tag):
+    """BASELINE configuration 2 size (4096 rays x 256 samples = 1,048,576 MLP evaluations), where
+    the CPU oracle would take minutes: size-independent properties instead.
+      * fused ray path == explicit points path + compositing kernel (bitwise in colors);
+      * gradients are linear in the upstream gradient: scaling by 2 is exact in fp32, so the
+        result must be bit-identical times 2;
+      * two runs are bit-identical (no atomics anywhere);
+      * a 64-ray slice agrees with the oracle."""
+    from nerf.rendering import render_nerf, composite_volume
+    model, params = make_model(tag)
+    R, S = 4096, 256
+    o, d = rays(R, 31)
+    o, d = o.to(DEV), d.to(DEV)
+    u = torch.rand(S, generator=torch.Generator().manual_seed(32)).to(DEV)
+    tgt = torch.rand(R, 3, generator=torch.Generator().manual_seed(33)).to(DEV)
+
+    def grads_of(scale):
+        model.zero_grad(set_to_none=True)
+        rgb = render_nerf(model, o, d, 2.0, 6.0, num_samples=S, device=DEV, chunk_size=8192, u=[u])
+        (torch.nn.functional.mse_loss(rgb, tgt) * scale).backward()
+        return rgb.detach(), torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+
+    rgb1, g1 = grads_of(1.0)
+    rgb2, g2 = grads_of(2.0)
+    rgb3, g3 = grads_of(1.0)
+    assert torch.equal(rgb1, rgb3) and torch.equal(g1, g3)
+    assert torch.equal(g2, 2 * g1)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    assert float(rgb1.min()) >= -1e-5 and float(rgb1.max()) <= 1 + 1e-5
+
+    t, deltas = hip.stratified_t(2.0, 6.0, S, u)
+    with torch.no_grad():
+        pos = hip.sample_positions(o, d, t, True, 2.0, 6.0).reshape(-1, 3)
+        dirs = d.unsqueeze(1).expand(-1, S, -1).reshape(-1, 3).contiguous()
+        colors, dens = model(pos, dirs)
+        rgb_unfused = composite_volume(colors.view(R, S, 3), dens.view(R, S), deltas, True)
+    assert torch.equal(rgb_unfused, rgb1)
+
+    fwd = oracle_fwd(tag)
+    ref = O.render(lambda x, v: fwd(params, x, v), o[:64].cpu(), d[:64].cpu(), 2.0, 6.0, S, [u.cpu()])
+    assert rel(rgb1[:64], ref) < RTOL
+
+
+# ----------------------------------------------------------------------------- hierarchical sampling
+def test_sample_pdf_indices_bit_exact(hip):
+    """No counterpart in the reference (parity unpinned): checked against the canonical-NeRF
+    restatement in the oracle.  Indices are bit-exact given the same CDF and draws."""
+    g = torch.Generator().manual_seed(5)
+    R, B, N = 257, 63, 128
+    t = O.stratified_t(2.0, 6.0, B + 1, torch.rand(B + 1, generator=g))
+    bins = t.expand(R, B + 1).contiguous()
+    w = torch.rand(R, B, generator=g) ** 4
+    w[3] = 0.0
+    u = torch.rand(R, N, generator=g)
+    u[5, :4] = torch.tensor([0.0, 1.0 - 1e-7, 0.5, 0.25])
+    wp = w + 1e-5
+    pdf = wp / wp.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros(R, 1), torch.cumsum(pdf, -1)], -1)
+    s_ref, idx_ref = O.sample_pdf(bins, w, u)
+    s, idx = hip.sample_pdf(bins.to(DEV), cdf.to(DEV), u.to(DEV))
+    assert torch.equal(idx.cpu().long(), idx_ref)
+    assert (s.cpu() - s_ref).abs().max() <= 1e-5
+    cdf_gpu = hip.weights_to_cdf(w.to(DEV))
+    assert (cdf_gpu.cpu() - cdf).abs().max() <= 2e-6
