@@ -24,6 +24,18 @@ constexpr int ACT_FLOATS = lay::TILE * LDA;
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIN = 2 };
 
+#ifndef NERF_EXP
+#define NERF_EXP 0   // diagnostic timing builds only: 1 no epilogue LDS writes, 2 no layer barriers, 4 one WG per CU
+#endif
+#if (NERF_EXP & 2)
+#define LAYER_SYNC() ((void)0)
+#else
+#define LAYER_SYNC() __syncthreads()
+#endif
+#ifndef STAGGER_SLEEPS
+#define STAGGER_SLEEPS 5   // x 127*64 cycles: about half of one 256x256 layer on a shared pipe
+#endif
+
 __device__ __forceinline__ f32x16 splat16(float v) {
     f32x16 r;
 #pragma unroll
@@ -31,8 +43,36 @@ __device__ __forceinline__ f32x16 splat16(float v) {
     return r;
 }
 
+// One K block of MFMAs for the wave's 64 x (32*NT) tile: 4 steps x 2 x NT instructions.
+template <int NT>
+__device__ __forceinline__ void mma_block(const f32x4 (&a)[2], const f32x4 (&b)[NT], f32x16 (&acc)[2][NT]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+}
+
+template <int NT>
+__device__ __forceinline__ void load_b(const float* __restrict__ b_ptr, int kb, size_t kb_stride, f32x4 (&b)[NT]) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b_ptr + kb * kb_stride + ni * 256);
+}
+__device__ __forceinline__ void load_a(const float* a_ptr, int kb, f32x4 (&a)[2]) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a_ptr + mi * 32 * LDA + kb * 8);
+}
+
 // acc[mi][ni] (+)= act[rows 32*mi.., k < 8*kb_count] * img, img = packed image with `n_img`
-// columns per K block; this wave's first column is ncol0.
+// columns per K block; this wave's first column is ncol0.  kb_count must be even.
+//
+// Software-pipelined by hand with two named fragment sets, pinned with sched_barrier: the loads
+// of K block kb+1 are issued BEFORE the 16 MFMAs (about 1000 cycles) of block kb.  Left to itself
+// the compiler sinks each load to just before its first use and pays the L2 latency of the weight
+// fetch on every block.  (A three-block-deep ring was measured and is not faster.)  The loop is
+// deliberately not unrolled further: twelve fully unrolled layers are ~90 KB of code.
 template <int NT>
 __device__ __forceinline__ void mma_layer(const float* act, const float* __restrict__ img, int n_img, int kb_count,
                                           int ncol0, int lane, f32x16 (&acc)[2][NT]) {
@@ -40,29 +80,23 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
     const float* a_ptr = act + r * LDA + 4 * h;
     const float* b_ptr = img + (size_t)(ncol0 + r) * 8 + 4 * h;
     const size_t kb_stride = (size_t)n_img * 8;
-    f32x4 a_cur[2], b_cur[NT], a_nxt[2], b_nxt[NT];
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) b_cur[ni] = *reinterpret_cast<const f32x4*>(b_ptr + ni * 256);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) a_cur[mi] = *reinterpret_cast<const f32x4*>(a_ptr + mi * 32 * LDA);
-    for (int kb = 0; kb < kb_count; ++kb) {
-        const int kn = (kb + 1 < kb_count) ? kb + 1 : kb;  // clamped prefetch of the next K block
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-            b_nxt[ni] = *reinterpret_cast<const f32x4*>(b_ptr + kn * kb_stride + ni * 256);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) a_nxt[mi] = *reinterpret_cast<const f32x4*>(a_ptr + mi * 32 * LDA + kn * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NT; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mi][j], b_cur[ni][j], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) b_cur[ni] = b_nxt[ni];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) a_cur[mi] = a_nxt[mi];
+    const int last = kb_count - 1;
+    f32x4 a0[2], a1[2], b0[NT], b1[NT];
+    load_b<NT>(b_ptr, 0, kb_stride, b0);
+    load_a(a_ptr, 0, a0);
+#pragma unroll 1
+    for (int kb = 0; kb < kb_count; kb += 2) {
+        load_b<NT>(b_ptr, kb + 1, kb_stride, b1);
+        load_a(a_ptr, kb + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_block<NT>(a0, b0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kn = min(kb + 2, last);  // clamped: the tail prefetch re-reads the last block
+        load_b<NT>(b_ptr, kn, kb_stride, b0);
+        load_a(a_ptr, kn, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_block<NT>(a1, b1, acc);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -102,7 +136,11 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                     nerf_sincosf(v, &s, &c);
                     v = s;
                 }
+#if (NERF_EXP & 1)
+                asm volatile("" ::"v"(v));
+#else
                 act[row * LDA + col] = v;
+#endif
                 if constexpr (STORE_COS && ACT == ACT_SIN) gcos[(size_t)row * ldg + col] = c;
             }
         }
@@ -148,6 +186,23 @@ __device__ __forceinline__ void encode_axis(float* dst, int axis, float x) {
         nerf_sincosf(mul_rn((float)(1 << j), x), &s, &c);
         dst[3 + 6 * j + axis] = s;
         dst[3 + 6 * j + 3 + axis] = c;
+    }
+}
+
+// Two workgroups share every CU (and every SIMD's matrix pipe).  Launched together and running
+// the same program on equal tiles they stay in lockstep: both reach their epilogues (no MFMA
+// work) at the same time and the pipe idles.  The second half of the first resident wave of
+// workgroups therefore starts half a layer late; every tile takes the same time, so the
+// offset persists for the whole launch.  Placement is only a speed matter, never correctness.
+__device__ __forceinline__ void stagger_second_resident_group() {
+    if (blockIdx.x < 512u) {
+        // HW_REG_HW_ID (register 4) bits [3:0]: this wave's slot on its SIMD; the two workgroups
+        // that share a CU in the first resident generation sit in slots of different parity
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        if (slot & 1u) {
+#pragma unroll 1
+            for (int i = 0; i < STAGGER_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
+        }
     }
 }
 

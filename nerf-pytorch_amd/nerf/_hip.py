@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnerf_hip.so")
+LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libnerf_hip.so")
 
 MODEL_NERF = 0
 MODEL_SIREN = 1

@@ -1,0 +1,173 @@
+// Practical fp32-MFMA ceiling on this device: register-only loop vs a loop shaped like the MLP
+// kernel's K block (2 LDS fragment reads + 2 global fragment loads per 16 MFMAs).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void reg_only(float* out, int iters, float seed) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+    float a = seed + threadIdx.x * 1e-3f, b = seed * 0.5f + threadIdx.x * 2e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0; for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) s += acc[i][k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256, 2) void shaped(float* out, const float* __restrict__ w, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 260; i += 256) lds[i] = (float)(i % 97) * 1e-3f;
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+    const float* ap = lds + (lane & 31) * 260 + 4 * (lane >> 5);
+    const float* bp = w + (size_t)(wave * 64 + (lane & 31)) * 8 + 4 * (lane >> 5);
+    f32x4 a0[2], b0[2], a1[2], b1[2];
+    auto ld = [&](int kb, f32x4 (&a)[2], f32x4 (&b)[2]) {
+        for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bp + (size_t)kb * 2048 + ni * 256);
+        for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(ap + mi * 32 * 260 + kb * 8);
+    };
+    auto mm = [&](f32x4 (&a)[2], f32x4 (&b)[2]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+    };
+    for (int it = 0; it < iters; ++it) {
+        ld(0, a0, b0);
+        for (int kb = 0; kb < 32; kb += 2) {
+            ld(kb + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            ld(kb + 2 < 32 ? kb + 2 : kb, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 16; ++k) s += acc[i][j][k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void layered(float* out, const float* __restrict__ w, int layers, int nimg) {
+    // MODE bit0: barriers around an LDS-writing epilogue; bit1: different weight image per layer (nimg images);
+    // bit2: bias load into the accumulators at layer start
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 260; i += 256) lds[i] = (float)(i % 97) * 1e-3f;
+    __syncthreads();
+    const float* ap = lds + (lane & 31) * 260 + 4 * (lane >> 5);
+    f32x4 a0[2], b0[2], a1[2], b1[2];
+    float s = 0;
+    for (int l = 0; l < layers; ++l) {
+        const float* img = w + ((MODE & 2) ? (size_t)((l + blockIdx.x) % nimg) * 65536 : 0);
+        const float* bp = img + (size_t)(wave * 64 + (lane & 31)) * 8 + 4 * (lane >> 5);
+        f32x16 acc[2][2];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
+            float bias = (MODE & 4) ? img[wave * 64 + 32 * j + (lane & 31)] : 0.f;
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = bias;
+        }
+        auto ld = [&](int kb, f32x4 (&a)[2], f32x4 (&b)[2]) {
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bp + (size_t)kb * 2048 + ni * 256);
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(ap + mi * 32 * 260 + kb * 8);
+        };
+        auto mm = [&](f32x4 (&a)[2], f32x4 (&b)[2]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+        };
+        ld(0, a0, b0);
+#pragma unroll 1
+        for (int kb = 0; kb < 32; kb += 2) {
+            ld(kb + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            ld(kb + 2 < 32 ? kb + 2 : kb, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE & 1) {
+            __syncthreads();
+            for (int mi = 0; mi < 2; ++mi) for (int ni = 0; ni < 2; ++ni) for (int g = 0; g < 16; ++g) {
+                int row = 32 * mi + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5), col = wave * 64 + 32 * ni + (lane & 31);
+                lds[row * 260 + col] = fmaxf(acc[mi][ni][g], 0.f) * 1e-3f;
+            }
+            __syncthreads();
+        } else {
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 16; ++k) s += acc[i][j][k];
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = s + lds[threadIdx.x];
+}
+
+template <int MODE>
+int run_layered(const char* name, float* out, const float* w, hipEvent_t e0, hipEvent_t e1, int grid) {
+    int layers = 400;
+    CK(hipFuncSetAttribute((const void*)layered<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 66560));
+    layered<MODE><<<grid, 256, 66560>>>(out, w, 20, 12);
+    CK(hipEventRecord(e0)); layered<MODE><<<grid, 256, 66560>>>(out, w, layers, 12); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s %8.3f ms  %7.1f TFLOP/s\n", name, ms, (double)grid * 4 * layers * 32 * 16 * 4096.0 / ms / 1e9);
+    return 0;
+}
+
+int main() {
+    float *out, *w;
+    CK(hipMalloc(&out, 2048 * 256 * 4));
+    CK(hipMalloc(&w, 12 * 65536 * 4));
+    CK(hipMemset(w, 0, 12 * 65536 * 4));
+    std::vector<float> hw(65536);
+    for (int i = 0; i < 65536; ++i) hw[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+    CK(hipMemcpy(w, hw.data(), 65536 * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto report = [&](const char* name, double flop, float ms) { printf("%-28s %8.3f ms  %7.1f TFLOP/s\n", name, ms, flop / ms / 1e9); };
+    for (int rep = 0; rep < 2; ++rep) {
+        {   // one wave per SIMD: 256 blocks of 256 threads
+            int iters = 20000;
+            CK(hipEventRecord(e0)); reg_only<1><<<256, 256>>>(out, iters, 1.0f); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            report("reg-only 1 wave/SIMD", 256.0 * 4 * iters * 16 * 4096.0, ms);
+        }
+        {   // two waves per SIMD
+            int iters = 10000;
+            CK(hipEventRecord(e0)); reg_only<2><<<512, 256>>>(out, iters, 1.0f); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            report("reg-only 2 waves/SIMD", 512.0 * 4 * iters * 16 * 4096.0, ms);
+        }
+        {
+            int iters = 400;
+            CK(hipFuncSetAttribute((const void*)shaped, hipFuncAttributeMaxDynamicSharedMemorySize, 66560));
+            CK(hipEventRecord(e0)); shaped<<<512, 256, 66560>>>(out, w, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            report("MLP-shaped K loop 2 WG/CU", 512.0 * 4 * iters * 32 * 16 * 4096.0, ms);
+        }
+    }
+    run_layered<0>("layered: plain (no epilogue)", out, w, e0, e1, 512);
+    run_layered<1>("layered: + barriers + LDS epilogue", out, w, e0, e1, 512);
+    run_layered<3>("layered: + 12 weight images", out, w, e0, e1, 512);
+    run_layered<7>("layered: + bias loads", out, w, e0, e1, 512);
+    run_layered<7>("layered: all, grid 256", out, w, e0, e1, 256);
+    run_layered<0>("layered: plain, grid 256", out, w, e0, e1, 256);
+    return 0;
+}
