@@ -275,7 +275,27 @@ __global__ __launch_bounds__(256) void thin_kernel(ThinArgs a) {
     const int64_t r0 = a.Mp * bid / G, r1 = a.Mp * (bid + 1) / G;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, ps = 0.f, qs[4] = {0.f, 0.f, 0.f, 0.f};
     if (tid < a.AW) {
-        for (int64_t m = r0; m < r1; ++m) {
+        constexpr int U = 8;  // rows in flight per thread: the loop is latency-bound otherwise
+        int64_t m = r0;
+        for (; m + U <= r1; m += U) {
+            float p[U], q[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                p[u] = a.P[(m + u) * a.ldp + tid];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) q[u][b] = b < a.NB ? a.Q[(m + u) * a.ldq + b] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ps += p[u];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    acc[b] = fmaf(p[u], q[u][b], acc[b]);
+                    qs[b] += q[u][b];
+                }
+            }
+        }
+        for (; m < r1; ++m) {
             const float p = a.P[m * a.ldp + tid];
             ps += p;
 #pragma unroll
@@ -354,7 +374,7 @@ void thin(Ctx& c, const float* P, int ldp, int AW, const float* Q, int ldq, int 
           float* db_wide, float* db_thin) {
     if (c.rc) return;
     int64_t G = (int64_t)c.Mp / 64;
-    if (G > 1024) G = 1024;
+    if (G > 512) G = 512;
     float* pslab = c.slab + (size_t)G * NB * AW;
     float* qslab = pslab + (size_t)G * AW;
     ThinArgs a{P, Q, ldp, ldq, AW, NB, (int64_t)c.Mp, c.slab, db_wide ? pslab : nullptr, db_thin ? qslab : nullptr};
