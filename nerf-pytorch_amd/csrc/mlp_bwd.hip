@@ -74,12 +74,15 @@ __device__ __forceinline__ void head_bwd(const BwdArgs& a, size_t m0, float* act
 template <int MASK, bool RANK1>
 __device__ __forceinline__ void dgrad_layer(float* act, const float* __restrict__ timg, int kb_count, int ncol0,
                                             int lane, const float* hsrc, float* gout, const float* dsig_s,
-                                            const float* __restrict__ sigw) {
+                                            const float* __restrict__ sigw,
+                                            const unsigned long long* __restrict__ mask_word = nullptr) {
     f32x16 acc[2][2];
     init_bias<2>(acc, nullptr, ncol0, lane);
+    unsigned long long bits = 0ull;
+    if constexpr (MASK == 3) bits = *mask_word;  // one 8-byte load, in flight during the whole K loop
     mma_layer<2>(act, timg, lay::H, kb_count, ncol0, lane, acc);
     __syncthreads();
-    bwd_epilogue<2, MASK, RANK1>(act, acc, ncol0, lane, hsrc, gout, lay::H, dsig_s, sigw);
+    bwd_epilogue<2, MASK, RANK1>(act, acc, ncol0, lane, hsrc, gout, lay::H, dsig_s, sigw, bits);
     __syncthreads();
 }
 
@@ -104,13 +107,16 @@ __global__ __launch_bounds__(256, 2) void nerf_dgrad_kernel(BwdArgs a) {
     __syncthreads();
     // rgb_head.0 (feature part): reduce over its 128 outputs -> gradient of the 256 features
     dgrad_layer<0, false>(act, pk + D10, HH / 8, ncol0, lane, nullptr, bw + BW_DZ9 * Mp + m0 * H, nullptr, nullptr);
+    auto mskp = [&](int l) {
+        return reinterpret_cast<const unsigned long long*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid;
+    };
     // block2.8: 256 feature rows on MFMA + the density row as a rank-1 term, ReLU mask of h8
-    dgrad_layer<1, true>(act, pk + d_img(9), H / 8, ncol0, lane, ws + (WS_H + 8 * (size_t)H) * Mp + m0 * H,
-                         bw + (BW_DZ + 8 * (size_t)H) * Mp + m0 * H, dsig_s, pk + SIGW);
+    dgrad_layer<3, true>(act, pk + d_img(9), H / 8, ncol0, lane, nullptr, bw + (BW_DZ + 8 * (size_t)H) * Mp + m0 * H,
+                         dsig_s, pk + SIGW, mskp(8));
     // layers 8..1 -> dz7..dz0 (layer 5 only through its feature columns)
     for (int l = 8; l >= 1; --l)
-        dgrad_layer<1, false>(act, pk + d_img(l), H / 8, ncol0, lane, ws + (WS_H + (size_t)(l - 1) * H) * Mp + m0 * H,
-                              bw + (BW_DZ + (size_t)(l - 1) * H) * Mp + m0 * H, nullptr, nullptr);
+        dgrad_layer<3, false>(act, pk + d_img(l), H / 8, ncol0, lane, nullptr,
+                              bw + (BW_DZ + (size_t)(l - 1) * H) * Mp + m0 * H, nullptr, nullptr, mskp(l - 1));
 }
 
 __global__ __launch_bounds__(256, 2) void siren_dgrad_kernel(BwdArgs a) {

@@ -117,9 +117,12 @@ __device__ __forceinline__ int acc_row(int mi, int g, int lane) { return 32 * mi
 // The post-activation tile itself goes to the workspace afterwards through store_tile
 // (whole rows, 16 B per lane); for sine layers (training) the derivative cos(z) has no LDS
 // home and is stored from the accumulator layout: gcos = row 0 of this tile, [64][ldg].
+// relu_mask (may be NULL): receives this lane's 64 (v > 0) bits, accumulator order.
 template <int NT, int ACT, bool STORE_COS>
 __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], int ncol0, int lane,
-                                             float* __restrict__ gcos, int ldg) {
+                                             float* __restrict__ gcos, int ldg,
+                                             unsigned long long* __restrict__ relu_mask = nullptr) {
+    unsigned mlo = 0u, mhi = 0u;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -130,7 +133,16 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                 const int row = acc_row(mi, g, lane);
                 float v = acc[mi][ni][g];
                 float c = 0.f;
-                if constexpr (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                if constexpr (ACT == ACT_RELU) {
+                    v = fmaxf(v, 0.0f);
+                    if constexpr (NT == 2) {
+                        constexpr unsigned dummy = 0;
+                        (void)dummy;
+                        const int bit = (mi * NT + ni) * 16 + g;
+                        if (bit < 32) mlo |= (v > 0.0f) ? (1u << (bit & 31)) : 0u;
+                        else mhi |= (v > 0.0f) ? (1u << (bit & 31)) : 0u;
+                    }
+                }
                 if constexpr (ACT == ACT_SIN) {
                     float s;
                     nerf_sincosf(v, &s, &c);
@@ -144,17 +156,23 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                 if constexpr (STORE_COS && ACT == ACT_SIN) gcos[(size_t)row * ldg + col] = c;
             }
         }
+    if constexpr (ACT == ACT_RELU && NT == 2) {
+        if (relu_mask) *relu_mask = ((unsigned long long)mhi << 32) | mlo;
+    }
 }
 
 // Backward epilogue: dX = acc (+ rank-1 term) times the activation derivative, written to
 // LDS (next layer's dY) and to the backward workspace (for the weight gradient).
 //   MASK 1: derivative = (hsrc > 0)         (ReLU; hsrc = the stored post-activation input)
 //   MASK 2: derivative = hsrc               (sine; hsrc = stored w0*cos(w0 z))
+//   MASK 3: derivative = bit of `bits`      (ReLU; the forward's per-lane mask word)
 //   MASK 0: none
 template <int NT, int MASK, bool RANK1>
 __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], int ncol0, int lane,
                                              const float* __restrict__ hsrc, float* __restrict__ gout, int ldg,
-                                             const float* dsig_lds, const float* __restrict__ sigw) {
+                                             const float* dsig_lds, const float* __restrict__ sigw,
+                                             unsigned long long bits = 0ull) {
+    const unsigned blo = (unsigned)bits, bhi = (unsigned)(bits >> 32);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -169,6 +187,10 @@ __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                 if constexpr (RANK1) v = fmaf(dsig_lds[row], sw, v);
                 if constexpr (MASK == 1) v = hsrc[(size_t)row * ldg + col] > 0.0f ? v : 0.0f;
                 if constexpr (MASK == 2) v = v * hsrc[(size_t)row * ldg + col];
+                if constexpr (MASK == 3) {
+                    const int bit = (mi * NT + ni) * 16 + g;
+                    v = (((bit < 32 ? blo : bhi) >> (bit & 31)) & 1u) ? v : 0.0f;
+                }
                 act[row * LDA + col] = v;
                 gout[(size_t)row * ldg + col] = v;
             }

@@ -272,7 +272,7 @@ __device__ unsigned long long g_stamps[1024][32];
 template <int ACT, bool TRAIN>
 __device__ __forceinline__ void hidden_layer(float* act, const float* __restrict__ img, int kb_count,
                                              const float* __restrict__ bias, int ncol0, int tid, float* gout,
-                                             float* gcos) {
+                                             float* gcos, unsigned long long* relu_mask = nullptr) {
     const int lane = tid & 63;
     f32x16 acc[2][2];
     init_bias<2>(acc, bias, ncol0, lane);
@@ -280,7 +280,7 @@ __device__ __forceinline__ void hidden_layer(float* act, const float* __restrict
     STAMP(20 + (kb_count == 32 ? 0 : 4));
     LAYER_SYNC();
     STAMP(21 + (kb_count == 32 ? 0 : 4));
-    fwd_epilogue<2, ACT, TRAIN>(act, acc, ncol0, lane, gcos, lay::H);
+    fwd_epilogue<2, ACT, TRAIN>(act, acc, ncol0, lane, gcos, lay::H, TRAIN ? relu_mask : nullptr);
     STAMP(22 + (kb_count == 32 ? 0 : 4));
     LAYER_SYNC();
     STAMP(23 + (kb_count == 32 ? 0 : 4));
@@ -304,6 +304,10 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
     float* ws = a.ws;
     const size_t Mp = a.Mp;
     auto wsp = [&](size_t off, int width) -> float* { return TRAIN ? ws + off * Mp + m0 * width : nullptr; };
+    // this lane's ReLU mask word of layer l (training only)
+    auto mskp = [&](int l) -> unsigned long long* {
+        return TRAIN ? reinterpret_cast<unsigned long long*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid : nullptr;
+    };
 
     STAMP(0);
 #if (NERF_EXP & 8)
@@ -322,12 +326,12 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
 
     const int ncol0 = wave * 64;
     // L0: K 64
-    hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L0, PE_P / 8, pk + BIAS, ncol0, tid, wsp(WS_H, H), nullptr);
+    hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L0, PE_P / 8, pk + BIAS, ncol0, tid, wsp(WS_H, H), nullptr, mskp(0));
     STAMP(3);
     // L1..L4
     for (int l = 1; l <= 4; ++l) {
         hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
-                                      tid, wsp(WS_H + (size_t)l * H, H), nullptr);
+                                      tid, wsp(WS_H + (size_t)l * H, H), nullptr, mskp(l));
         STAMP(3 + l);
     }
     // L5: [h4 | pe] in two passes over the same accumulators
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         __syncthreads();
         mma_layer<2>(act, pk + F_L5B, H, PE_P / 8, ncol0, lane, acc);
         __syncthreads();
-        fwd_epilogue<2, ACT_RELU, false>(act, acc, ncol0, lane, nullptr, H);
+        fwd_epilogue<2, ACT_RELU, false>(act, acc, ncol0, lane, nullptr, H, mskp(5));
         __syncthreads();
         if constexpr (TRAIN) store_tile(act, H, wsp(WS_H + 5 * (size_t)H, H), H, tid);
     }
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
     // L6..L8
     for (int l = 6; l <= 8; ++l)
         hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L6 + (size_t)(l - 6) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
-                                      tid, wsp(WS_H + (size_t)l * H, H), nullptr);
+                                      tid, wsp(WS_H + (size_t)l * H, H), nullptr, mskp(l));
     STAMP(9);
     // L9: 256 feature columns on MFMA, density column on the VALU
     {

@@ -60,9 +60,14 @@ constexpr size_t PACKED_FLOATS = D9 + 9 * img(H, H);
 constexpr size_t d_img(int layer) { return D9 + (size_t)(9 - layer) * img(H, H); }  // layer 1..9
 
 // ---- forward workspace (floats per padded sample), rows of the padded sample count Mp
-// pe [64] | de [32] | h0..h8 [9][256] | f [256] | g [128] | sraw [1]
-constexpr size_t WS_PE = 0, WS_DE = 64, WS_H = 96, WS_F = WS_H + 9 * H, WS_G = WS_F + H, WS_SRAW = WS_G + HH;
-constexpr size_t WS_PER_SAMPLE = WS_SRAW + 1;
+// pe [64] | de [32] | h0..h8 [9][256] | f [256] | g [128] | sraw [1] | relu masks [9][8]
+// The masks are the (h > 0) bits of h0..h8 in the accumulator layout of the tile kernels: per
+// layer and 64-sample tile 256 lanes x one 64-bit word (bit (2*mi+ni)*16+g of lane l = element
+// acc[mi][ni][g] of that lane), i.e. 8 floats' worth per sample.  The data-gradient kernel reads
+// them with ONE 8-byte load per lane and layer instead of re-reading h (1 KB per sample).
+constexpr size_t WS_PE = 0, WS_DE = 64, WS_H = 96, WS_F = WS_H + 9 * H, WS_G = WS_F + H, WS_SRAW = WS_G + HH,
+                 WS_MASK = WS_SRAW + 1;
+constexpr size_t WS_PER_SAMPLE = WS_MASK + 9 * 8;
 // ---- backward workspace: dz0..dz8 [9][256] | dz9 [256] | dz10 [128] | dz11 [4] | dsig [1]
 constexpr size_t BW_DZ = 0, BW_DZ9 = 9 * H, BW_DZ10 = BW_DZ9 + H, BW_DZ11 = BW_DZ10 + HH, BW_DSIG = BW_DZ11 + 4;
 constexpr size_t BW_PER_SAMPLE = BW_DSIG + 1;

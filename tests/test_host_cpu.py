@@ -31,7 +31,7 @@ def test_sizes_match_reference_parameter_counts():
     from nerf.models import NeRF, Siren
     assert _hip.param_floats(_hip.MODEL_NERF) == 661636 == sum(p.numel() for p in NeRF().parameters())
     assert _hip.param_floats(_hip.MODEL_SIREN) == 564356 == sum(p.numel() for p in Siren().parameters())
-    assert _hip.lib.nerf_mlp_fwd_workspace_floats(0, 100) == 128 * (64 + 32 + 9 * 256 + 256 + 128 + 1)
+    assert _hip.lib.nerf_mlp_fwd_workspace_floats(0, 100) == 128 * (64 + 32 + 9 * 256 + 256 + 128 + 1 + 72)
     assert _hip.lib.nerf_mlp_fwd_workspace_floats(0, -1) == 0
     assert _hip.lib.nerf_mlp_packed_floats(7) == 0
 
