@@ -181,6 +181,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
     const int G = gridDim.x, bid = blockIdx.x;
     const int c0 = (int)((int64_t)a.nchunks * bid / G), c1 = (int)((int64_t)a.nchunks * (bid + 1) / G);
     const bool active = wave < WN * WK;
+    const bool late = active && wave >= 4;
     const int wn = wave / WK, wk = wave % WK;
     const int r = lane & 31, h = lane >> 5;
 
@@ -224,27 +225,45 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
         const bool more = c + 1 < c1;
         if (more) gload(c + 1);
         if (active) {
-            const float* ap = buf + wn * (NW / WN) + r;
-            const float* bp = buf + NW + wk * (KW / WK) + r;
-#pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-                float av[TN], bv[TK];
+            const float* ap = buf + wn * (NW / WN) + r + h * ROWF;
+            const float* bp = buf + NW + wk * (KW / WK) + r + h * ROWF;
+            // fragments of sample pair s+1 are read from LDS before the MFMAs of pair s (two named
+            // register sets, pinned): otherwise every 4-8 MFMAs wait for an LDS round trip
+            float av0[TN], bv0[TK], av1[TN], bv1[TK];
+            auto lds_frags = [&](int s, float (&av)[TN], float (&bv)[TK]) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) av[i] = ap[(2 * s + h) * ROWF + 32 * i];
+                for (int i = 0; i < TN; ++i) av[i] = ap[2 * s * ROWF + 32 * i];
 #pragma unroll
-                for (int j = 0; j < TK; ++j) bv[j] = bp[(2 * s + h) * ROWF + 32 * j];
+                for (int j = 0; j < TK; ++j) bv[j] = bp[2 * s * ROWF + 32 * j];
+            };
+            auto mma = [&](float (&av)[TN], float (&bv)[TK]) {
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int j = 0; j < TK; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            };
+            lds_frags(0, av0, bv0);
+#pragma unroll
+            for (int s = 0; s < 16; s += 2) {
+                // waves 4-7 share their SIMDs with waves 0-3: they stage the next chunk in the middle
+                // of their MFMA block, waves 0-3 at its end, so the two never leave a pipe idle together
+                if (s == 8 && more && late) lstore(nbuf);
+                lds_frags(s + 1, av1, bv1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(av0, bv0);
+                __builtin_amdgcn_sched_barrier(0);
+                lds_frags(s + 2 < 16 ? s + 2 : 15, av0, bv0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(av1, bv1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (a.bslab && tid < NW) {
 #pragma unroll 8
             for (int s = 0; s < 32; ++s) bsum += buf[s * ROWF + tid];
         }
-        if (more) lstore(nbuf);
+        if (more && !late) lstore(nbuf);
         __syncthreads();
     }
     if (active) {
