@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from .ops import MLPFunction, PackedWeights, _f32c
+from .ops import MLPFunction, PackedWeights, _f32c, wants_grad
 
 
 def _relu_stack(dims: List[int], last_act: bool) -> nn.Sequential:
@@ -64,7 +64,8 @@ class _FusedMLP(nn.Module):
         if points.dim() != 2 or points.shape[1] != 3 or rays_d.shape != points.shape:
             raise ValueError("points and rays_d must both be [M,3]")
         params = self.ordered_parameters()
-        return MLPFunction.apply(self.model_id, self.packed_weights(), _f32c(points), _f32c(rays_d), *params)
+        return MLPFunction.apply(self.model_id, self.packed_weights(), _f32c(points), _f32c(rays_d),
+                                 wants_grad(params), *params)
 
 
 class NeRF(_FusedMLP):

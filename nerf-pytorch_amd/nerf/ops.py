@@ -38,6 +38,13 @@ class PackedWeights:
         return self._img
 
 
+def wants_grad(params: Sequence[torch.Tensor]) -> bool:
+    """Training mode = autograd is recording and some parameter asks for a gradient.  Decided by
+    the caller: inside autograd.Function.forward grad mode is always off and needs_input_grad
+    ignores torch.no_grad()."""
+    return torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
+
 def _split_grads(flat: torch.Tensor, params: Sequence[torch.Tensor]):
     out, off = [], 0
     for p in params:
@@ -52,9 +59,8 @@ class MLPFunction(torch.autograd.Function):
     backward yields the 24 parameter gradients (flat buffer, state_dict order)."""
 
     @staticmethod
-    def forward(ctx, model_id, packed, points, dirs, *params):
+    def forward(ctx, model_id, packed, points, dirs, train, *params):
         M = points.shape[0]
-        train = any(ctx.needs_input_grad[4:])  # all False under no_grad or with frozen parameters
         colors, density, ws = _hip.mlp_fwd(model_id, packed, M, points=points, dirs=dirs, train=train)
         ctx.model_id, ctx.M, ctx.train = model_id, M, train
         ctx.nparams = len(params)
@@ -80,7 +86,7 @@ class MLPFunction(torch.autograd.Function):
                 n *= s
             grads.append(flat[off:off + n].view(shp))
             off += n
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class RenderFunction(torch.autograd.Function):
@@ -88,10 +94,9 @@ class RenderFunction(torch.autograd.Function):
     inside the MLP kernel, colors/densities go straight to the compositing kernel."""
 
     @staticmethod
-    def forward(ctx, model_id, packed, rays_o, rays_d, t, deltas, near, far, white, want_extras, *params):
+    def forward(ctx, model_id, packed, rays_o, rays_d, t, deltas, near, far, white, want_extras, train, *params):
         R, S = rays_o.shape[0], t.shape[0]
         M = R * S
-        train = any(ctx.needs_input_grad[10:])  # all False under no_grad or with frozen parameters
         colors, density, ws = _hip.mlp_fwd(model_id, packed, M, rays_o=rays_o, rays_d=rays_d, t=t, S=S, near=near,
                                            far=far, train=train)
         colors = colors.view(R, S, 3)
@@ -121,7 +126,7 @@ class RenderFunction(torch.autograd.Function):
                 n *= s
             grads.append(flat[off:off + n].view(shp))
             off += n
-        return (None,) * 10 + tuple(grads)
+        return (None,) * 11 + tuple(grads)
 
 
 class CompositeFunction(torch.autograd.Function):

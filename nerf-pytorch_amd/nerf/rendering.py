@@ -13,7 +13,7 @@ import torch
 from torch import Tensor
 
 from . import _hip
-from .ops import CompositeFunction, RenderFunction, _f32c
+from .ops import CompositeFunction, RenderFunction, _f32c, wants_grad
 
 
 def stratified_sampling(near: float, far: float, num_bins: int, device: str = 'cpu', *,
@@ -108,6 +108,7 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
         model._check_supported()
         params = model.ordered_parameters()
         packed = model.packed_weights()
+        train = wants_grad(params)
     outs, extras = [], []
     for ci, i in enumerate(range(0, rays_o.shape[0], chunk_size)):
         o_chunk = rays_o[i:i + chunk_size]
@@ -115,7 +116,7 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
         t, deltas = _t_and_deltas(near, far, num_samples, rays_o.device, None if u is None else u[ci].to(rays_o.device))
         if fused:
             res = RenderFunction.apply(model.model_id, packed, o_chunk, d_chunk, t, deltas, float(near), float(far),
-                                       bool(white_background), bool(return_extras), *params)
+                                       bool(white_background), bool(return_extras), train, *params)
             if return_extras:
                 outs.append(res[0])
                 extras.append(res[1:])
