@@ -50,6 +50,12 @@ int nerf_stratified_t(double near, double far, int S, const float* u, float* t, 
 int nerf_sample_positions(const float* rays_o, const float* rays_d, const float* t, int64_t R, int S,
                           int normalize, double near, double far, float* pos, void* stream);
 
+/* ---- pinhole rays: nerf/data.py:65-114 (compute_rays) -------------------------------------
+ * c2w [N,4,4] row-major camera-to-world matrices -> rays_o, rays_d [N, H*W, 3]: direction of
+ * pixel (u,v) = normalise(c2w[:3,:3] @ (u - W/2, -(v - H/2), -focal)), origin = c2w[:3,3]. */
+int nerf_compute_rays(const float* c2w, int64_t N, int H, int W, double focal, float* rays_o, float* rays_d,
+                      void* stream);
+
 /* ---- positional encoding: nerf/encoding.py:4-20 ----------------------------------------
  * out[m,:] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)], x: [M,D],
  * out: [M, D*(1+2L)], each sin/cos block D wide.  1 <= D <= 4, 0 <= L <= 16. */
@@ -63,6 +69,10 @@ int nerf_posenc_fwd(const float* x, int64_t M, int D, int L, float* out, void* s
 int nerf_composite_fwd(const float* colors, const float* densities, const float* deltas, const float* t,
                        int64_t R, int S, int white_background, float* rgb, float* weights, float* depth,
                        float* acc, void* stream);
+
+/* compute_accumulated_transmittance on its own (nerf/rendering.py:110-122): out[r,s] =
+ * prod_{j<s} betas[r,j], out[r,0] = 1.  betas, out: [R,S]. */
+int nerf_exclusive_cumprod(const float* betas, int64_t R, int S, float* out, void* stream);
 
 /* Gradient of nerf_composite_fwd's rgb wrt colors and densities (what autograd derives for
  * nerf/rendering.py:143-151, including ATen's zero-safe cumprod backward).

@@ -224,6 +224,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_bwd_kernel(
     }
 }
 
+// exclusive cumulative product along a ray (compute_accumulated_transmittance on its own)
+__global__ __launch_bounds__(64 * kWavesPerBlock) void excl_cumprod_kernel(const float* __restrict__ betas, int64_t R,
+                                                                          int S, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int per = (S + 63) / 64;
+    const int s0 = lane * per;
+    float prod = 1.0f;
+    for (int e = 0; e < per; ++e)
+        if (s0 + e < S) prod *= betas[r * S + s0 + e];
+    float T = wave_excl_prod(prod, lane);
+    for (int e = 0; e < per; ++e)
+        if (s0 + e < S) {
+            out[r * S + s0 + e] = T;
+            T *= betas[r * S + s0 + e];
+        }
+}
+
 template <int EPL>
 int launch_fwd(const float* colors, const float* dens, const float* deltas, const float* t, int64_t R, int S, int white,
                float* rgb, float* weights, float* depth, float* acc, hipStream_t st) {
@@ -300,4 +319,14 @@ extern "C" int nerf_composite_bwd(const float* colors, const float* densities, c
     if (epl <= 4) return launch_bwd<4>(colors, densities, deltas, R, S, white_background, grad_rgb, dcolors, ddensities, st);
     if (epl <= 8) return launch_bwd<8>(colors, densities, deltas, R, S, white_background, grad_rgb, dcolors, ddensities, st);
     return launch_bwd<16>(colors, densities, deltas, R, S, white_background, grad_rgb, dcolors, ddensities, st);
+}
+
+extern "C" int nerf_exclusive_cumprod(const float* betas, int64_t R, int S, float* out, void* stream) {
+    NERF_REQUIRE(R >= 0 && S >= 1, "nerf_exclusive_cumprod: bad R=%lld S=%d", (long long)R, S);
+    if (R == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(betas);
+    NERF_REQUIRE_PTR(out);
+    NERF_REQUIRE(ceil_div64(R, kWavesPerBlock) < (1ll << 31), "nerf_exclusive_cumprod: too many rays");
+    excl_cumprod_kernel<<<(unsigned)ceil_div64(R, kWavesPerBlock), 64 * kWavesPerBlock, 0, (hipStream_t)stream>>>(betas, R, S, out);
+    return nerf_check_launch("nerf_exclusive_cumprod");
 }

@@ -217,3 +217,45 @@ extern "C" int nerf_sample_pdf(const float* bins, const float* cdf, const float*
                                                                                       idx);
     return nerf_check_launch("nerf_sample_pdf");
 }
+
+// ---------------------------------------------------------------------------------------
+// pinhole rays (nerf/data.py:65-114 compute_rays): per pixel (u, v) of an H x W image,
+// camera-space direction (u - W/2, -(v - H/2), -focal), rotated by c2w[:3,:3], L2-normalised;
+// origin = c2w[:3,3].  c2w: [N][4][4] row-major.  One thread per ray, 24 B written.
+// ---------------------------------------------------------------------------------------
+__global__ void compute_rays_kernel(const float* __restrict__ c2w, int64_t N, int H, int W, float focal,
+                                    float* __restrict__ ro, float* __restrict__ rd) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)H * W;
+    if (idx >= N * per) return;
+    const int64_t n = idx / per;
+    const int64_t p = idx - n * per;
+    const int v = (int)(p / W), u = (int)(p - (int64_t)v * W);
+    const float x = (float)u - 0.5f * (float)W;
+    const float y = -((float)v - 0.5f * (float)H);
+    const float z = -focal;
+    const float* m = c2w + n * 16;
+    float d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = add_rn(add_rn(mul_rn(m[4 * i], x), mul_rn(m[4 * i + 1], y)), mul_rn(m[4 * i + 2], z));
+    const float nrm = sqrtf(add_rn(add_rn(mul_rn(d[0], d[0]), mul_rn(d[1], d[1])), mul_rn(d[2], d[2])));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        rd[idx * 3 + i] = div_rn(d[i], nrm);
+        ro[idx * 3 + i] = m[4 * i + 3];
+    }
+}
+
+extern "C" int nerf_compute_rays(const float* c2w, int64_t N, int H, int W, double focal, float* rays_o, float* rays_d,
+                                 void* stream) {
+    NERF_REQUIRE(N >= 0 && H >= 1 && W >= 1, "nerf_compute_rays: bad N=%lld H=%d W=%d", (long long)N, H, W);
+    if (N == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(c2w);
+    NERF_REQUIRE_PTR(rays_o);
+    NERF_REQUIRE_PTR(rays_d);
+    const int64_t total = N * H * W;
+    NERF_REQUIRE(ceil_div64(total, 256) < (1ll << 31), "nerf_compute_rays: too many rays");
+    compute_rays_kernel<<<(unsigned)ceil_div64(total, 256), 256, 0, (hipStream_t)stream>>>(c2w, N, H, W, (float)focal,
+                                                                                        rays_o, rays_d);
+    return nerf_check_launch("nerf_compute_rays");
+}

@@ -34,6 +34,8 @@ _SIGS = {
     "nerf_last_error": (c_char_p, []),
     "nerf_stratified_t": (c_int, [c_double, c_double, c_int, _P, _P, _P, _P]),
     "nerf_sample_positions": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_double, c_double, _P, _P]),
+    "nerf_compute_rays": (c_int, [_P, c_int64, c_int, c_int, c_double, _P, _P, _P]),
+    "nerf_exclusive_cumprod": (c_int, [_P, c_int64, c_int, _P, _P]),
     "nerf_posenc_fwd": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
     "nerf_composite_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "nerf_composite_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
@@ -140,6 +142,25 @@ def sample_positions(rays_o: torch.Tensor, rays_d: torch.Tensor, t: torch.Tensor
                                      int(normalize), float(near), float(far), _dev(pos, "pos"), _stream()),
            "nerf_sample_positions")
     return pos
+
+
+def compute_rays(c2w: torch.Tensor, H: int, W: int, focal: float):
+    """c2w [N,4,4] -> (rays_o, rays_d) [N, H*W, 3] on the device of c2w."""
+    if c2w.dim() != 3 or c2w.shape[1:] != (4, 4):
+        raise ValueError("c2w must be [N,4,4]")
+    N = c2w.shape[0]
+    ro = torch.empty((N, H * W, 3), dtype=torch.float32, device=c2w.device)
+    rd = torch.empty_like(ro)
+    _check(lib.nerf_compute_rays(_dev(c2w, "c2w"), N, H, W, float(focal), _dev(ro, "rays_o"), _dev(rd, "rays_d"),
+                                 _stream()), "nerf_compute_rays")
+    return ro, rd
+
+
+def exclusive_cumprod(betas: torch.Tensor) -> torch.Tensor:
+    R, S = betas.shape
+    out = torch.empty_like(betas)
+    _check(lib.nerf_exclusive_cumprod(_dev(betas, "betas"), R, S, _dev(out, "out"), _stream()), "nerf_exclusive_cumprod")
+    return out
 
 
 def posenc(x: torch.Tensor, L: int) -> torch.Tensor:

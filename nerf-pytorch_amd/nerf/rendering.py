@@ -55,15 +55,12 @@ def query_model(model: torch.nn.Module, sample_positions_flat: Tensor, direction
 
 
 def compute_accumulated_transmittance(betas: Tensor) -> Tensor:
-    """Exclusive cumulative product along dim 1 (reference rendering.py:110-122), obtained
-    from the compositing kernel: with alpha = 1-beta and a unit delta the kernel's weights are
-    T*alpha; T itself is returned by compositing all-ones colours... kept as a thin helper for
-    API parity: computed as weights/alpha is NOT safe, so use the scan directly."""
-    R, S = betas.shape
-    # densities d with exp(-d*1) = beta  <=>  the kernel's beta; to stay exact and zero-safe,
-    # run the kernel on sigma = -log(beta) only when needed by callers; default: torch scan.
-    inc = torch.cumprod(betas, dim=1)
-    return torch.cat((torch.ones_like(inc[:, :1]), inc[:, :-1]), dim=1)
+    """Exclusive cumulative product along dim 1: T[:,0] = 1, T[:,s] = prod_{j<s} betas[:,j]
+    (reference rendering.py:110-122); one ray per wavefront, forward only (inside the renderer
+    the transmittance and its gradient live in the compositing kernels)."""
+    if betas.requires_grad:
+        raise NotImplementedError("use composite_volume for a differentiable transmittance")
+    return _hip.exclusive_cumprod(_f32c(betas))
 
 
 def composite_volume(colors: Tensor, densities: Tensor, deltas: Tensor, white_background: bool) -> Tensor:
