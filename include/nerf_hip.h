@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 1
+#define NERF_ABI_VERSION 2
 
 #define NERF_OK 0
 #define NERF_E_ARG (-1)      /* bad shape / size / unsupported configuration */
@@ -65,10 +65,12 @@ int nerf_posenc_fwd(const float* x, int64_t M, int D, int L, float* out, void* s
  * composite_volume) ------------------------------------------------------------------------
  * colors [R,S,3], densities [R,S], deltas [S] -> rgb [R,3]; optional outputs (NULL to skip):
  * weights [R,S] (= T_excl(1-alpha)*alpha), depth [R] (= sum w*t, needs t [S]; no reference
- * counterpart), acc [R] (= sum w).  One ray per wavefront; 1 <= S <= 1024. */
+ * counterpart), acc [R] (= sum w).  One ray per wavefront; 1 <= S <= 1024.
+ * per_ray != 0: deltas and t are [R,S] (every ray has its own sample depths, as after
+ * hierarchical re-sampling) instead of one shared [S] vector. */
 int nerf_composite_fwd(const float* colors, const float* densities, const float* deltas, const float* t,
-                       int64_t R, int S, int white_background, float* rgb, float* weights, float* depth,
-                       float* acc, void* stream);
+                       int64_t R, int S, int per_ray, int white_background, float* rgb, float* weights,
+                       float* depth, float* acc, void* stream);
 
 /* compute_accumulated_transmittance on its own (nerf/rendering.py:110-122): out[r,s] =
  * prod_{j<s} betas[r,j], out[r,0] = 1.  betas, out: [R,S]. */
@@ -78,8 +80,8 @@ int nerf_exclusive_cumprod(const float* betas, int64_t R, int S, float* out, voi
  * nerf/rendering.py:143-151, including ATen's zero-safe cumprod backward).
  * grad_rgb [R,3] -> dcolors [R,S,3], ddensities [R,S]. */
 int nerf_composite_bwd(const float* colors, const float* densities, const float* deltas, int64_t R, int S,
-                       int white_background, const float* grad_rgb, float* dcolors, float* ddensities,
-                       void* stream);
+                       int per_ray, int white_background, const float* grad_rgb, float* dcolors,
+                       float* ddensities, void* stream);
 
 /* ---- MLP: nerf/models.py NeRF.forward :62-75, Siren.forward :185-203 ---------------------
  * Only the architecture the reference's callers build is supported: hidden 256, 10/4
@@ -103,15 +105,16 @@ int nerf_mlp_pack(int model, const float* const* params, float* packed, void* st
 /* Fused encode + MLP forward over M samples.
  * Inputs, one of:
  *   points != NULL: points [M,3] (already normalised), dirs [M,3]            (models.py forward)
- *   points == NULL: rays_o, rays_d [R,3], t [S], M = R*S; sample m belongs to ray m/S and
- *                   the position is generated and normalised in registers as
- *                   nerf/rendering.py:59-62,82 would (never materialised in HBM).
+ *   points == NULL: rays_o, rays_d [R,3], t [S] (t_per_ray == 0) or t [R,S] (t_per_ray != 0),
+ *                   M = R*S; sample m belongs to ray m/S and the position is generated and
+ *                   normalised in registers as nerf/rendering.py:59-62,82 would (never
+ *                   materialised in HBM).
  * Outputs: colors [M,3], density [M].
  * workspace: NULL for inference; else nerf_mlp_fwd_workspace_floats(model, M) floats that
  * nerf_mlp_bwd reads. */
 int nerf_mlp_fwd(int model, const float* packed, int64_t M, const float* points, const float* dirs,
-                 const float* rays_o, const float* rays_d, const float* t, int S, double near, double far,
-                 float* colors, float* density, float* workspace, void* stream);
+                 const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near,
+                 double far, float* colors, float* density, float* workspace, void* stream);
 
 /* Backward of nerf_mlp_fwd wrt the 24 parameter tensors.
  * dcolors [M,3], ddensity [M]: upstream gradients; colors: the forward's output.
@@ -140,8 +143,13 @@ int nerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int 
  * nerf_weights_to_cdf: weights [R,B] -> cdf [R,B+1] = [0, cumsum((w+1e-5)/sum(w+1e-5))].
  * nerf_sample_pdf: bins [R,B+1], cdf [R,B+1], u [R,N] -> samples [R,N] (linear interpolation
  * inside the bin) and idx [R,N] (int32: searchsorted(cdf, u, right=True); a pure comparison
- * result, bit-exact for identical cdf and u). */
+ * result, bit-exact for identical cdf and u).
+ * nerf_merge_samples: per ray, the sorted union of the shared coarse depths t_coarse [Sc] and
+ * that ray's fine depths t_fine [R,Sf] -> t_all [R,Sc+Sf] (ascending) and deltas [R,Sc+Sf]
+ * (successive differences, last = 1e10).  Sc+Sf <= 1024. */
 int nerf_weights_to_cdf(const float* weights, int64_t R, int B, float* cdf, void* stream);
+int nerf_merge_samples(const float* t_coarse, const float* t_fine, int64_t R, int Sc, int Sf, float* t_all,
+                       float* deltas, void* stream);
 int nerf_sample_pdf(const float* bins, const float* cdf, const float* u, int64_t R, int B, int N,
                     float* samples, int32_t* idx, void* stream);
 

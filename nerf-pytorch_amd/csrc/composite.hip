@@ -35,6 +35,7 @@ template <int EPL, bool VEC>
 __device__ __forceinline__ void load_ray(const float* __restrict__ colors, const float* __restrict__ dens,
                                          const float* __restrict__ deltas, int64_t r, int S, int lane,
                                          float (&sig)[EPL], float (&dl)[EPL], float (&col)[EPL][3]) {
+    // `deltas` already points at this ray's row when depths are per ray
     const int s0 = lane * EPL;
     if constexpr (VEC) {
         const f32x4* dp = reinterpret_cast<const f32x4*>(dens + r * S + s0);
@@ -73,12 +74,16 @@ __device__ __forceinline__ void load_ray(const float* __restrict__ colors, const
 template <int EPL, bool VEC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_fwd_kernel(
     const float* __restrict__ colors, const float* __restrict__ dens, const float* __restrict__ deltas,
-    const float* __restrict__ tvals, int64_t R, int S, int white, float* __restrict__ rgb,
+    const float* __restrict__ tvals, int64_t R, int S, int per_ray, int white, float* __restrict__ rgb,
     float* __restrict__ weights, float* __restrict__ depth, float* __restrict__ accout) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (r >= R) return;  // wave-uniform; no block barrier in this kernel
     float sig[EPL], dl[EPL], col[EPL][3];
+    if (per_ray) {
+        deltas += r * S;
+        if (tvals) tvals += r * S;
+    }
     load_ray<EPL, VEC>(colors, dens, deltas, r, S, lane, sig, dl, col);
 
     float alpha[EPL], beta[EPL];
@@ -128,11 +133,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_fwd_kernel(
 template <int EPL, bool VEC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_bwd_kernel(
     const float* __restrict__ colors, const float* __restrict__ dens, const float* __restrict__ deltas, int64_t R,
-    int S, int white, const float* __restrict__ grad_rgb, float* __restrict__ dcolors, float* __restrict__ ddens) {
+    int S, int per_ray, int white, const float* __restrict__ grad_rgb, float* __restrict__ dcolors,
+    float* __restrict__ ddens) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (r >= R) return;
     float sig[EPL], dl[EPL], col[EPL][3];
+    if (per_ray) deltas += r * S;
     load_ray<EPL, VEC>(colors, dens, deltas, r, S, lane, sig, dl, col);
     const float g0 = grad_rgb[r * 3 + 0], g1 = grad_rgb[r * 3 + 1], g2 = grad_rgb[r * 3 + 2];
     const float gbg = white ? (g0 + g1 + g2) : 0.0f;
@@ -244,24 +251,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void excl_cumprod_kernel(const
 }
 
 template <int EPL>
-int launch_fwd(const float* colors, const float* dens, const float* deltas, const float* t, int64_t R, int S, int white,
-               float* rgb, float* weights, float* depth, float* acc, hipStream_t st) {
+int launch_fwd(const float* colors, const float* dens, const float* deltas, const float* t, int64_t R, int S, int per_ray,
+               int white, float* rgb, float* weights, float* depth, float* acc, hipStream_t st) {
     const unsigned grid = (unsigned)ceil_div64(R, kWavesPerBlock);
     const bool vec = (EPL % 4 == 0) && (S == 64 * EPL) &&
                      ((((uintptr_t)colors | (uintptr_t)dens | (uintptr_t)deltas) & 15) == 0);
     if (vec) {
         if constexpr (EPL % 4 == 0)
-            composite_fwd_kernel<EPL, true><<<grid, 64 * kWavesPerBlock, 0, st>>>(colors, dens, deltas, t, R, S, white,
-                                                                                 rgb, weights, depth, acc);
+            composite_fwd_kernel<EPL, true><<<grid, 64 * kWavesPerBlock, 0, st>>>(colors, dens, deltas, t, R, S, per_ray,
+                                                                                 white, rgb, weights, depth, acc);
     } else {
-        composite_fwd_kernel<EPL, false><<<grid, 64 * kWavesPerBlock, 0, st>>>(colors, dens, deltas, t, R, S, white, rgb,
-                                                                              weights, depth, acc);
+        composite_fwd_kernel<EPL, false><<<grid, 64 * kWavesPerBlock, 0, st>>>(colors, dens, deltas, t, R, S, per_ray,
+                                                                              white, rgb, weights, depth, acc);
     }
     return nerf_check_launch("nerf_composite_fwd");
 }
 
 template <int EPL>
-int launch_bwd(const float* colors, const float* dens, const float* deltas, int64_t R, int S, int white,
+int launch_bwd(const float* colors, const float* dens, const float* deltas, int64_t R, int S, int per_ray, int white,
                const float* grad_rgb, float* dcolors, float* ddens, hipStream_t st) {
     const unsigned grid = (unsigned)ceil_div64(R, kWavesPerBlock);
     const bool vec = (EPL % 4 == 0) && (S == 64 * EPL) &&
@@ -269,10 +276,10 @@ int launch_bwd(const float* colors, const float* dens, const float* deltas, int6
                         (uintptr_t)ddens) & 15) == 0);
     if (vec) {
         if constexpr (EPL % 4 == 0)
-            composite_bwd_kernel<EPL, true><<<grid, 64 * kWavesPerBlock, 0, st>>>(colors, dens, deltas, R, S, white,
+            composite_bwd_kernel<EPL, true><<<grid, 64 * kWavesPerBlock, 0, st>>>(colors, dens, deltas, R, S, per_ray, white,
                                                                                  grad_rgb, dcolors, ddens);
     } else {
-        composite_bwd_kernel<EPL, false><<<grid, 64 * kWavesPerBlock, 0, st>>>(colors, dens, deltas, R, S, white,
+        composite_bwd_kernel<EPL, false><<<grid, 64 * kWavesPerBlock, 0, st>>>(colors, dens, deltas, R, S, per_ray, white,
                                                                               grad_rgb, dcolors, ddens);
     }
     return nerf_check_launch("nerf_composite_bwd");
@@ -281,8 +288,8 @@ int launch_bwd(const float* colors, const float* dens, const float* deltas, int6
 }  // namespace
 
 extern "C" int nerf_composite_fwd(const float* colors, const float* densities, const float* deltas, const float* t,
-                                  int64_t R, int S, int white_background, float* rgb, float* weights, float* depth,
-                                  float* acc, void* stream) {
+                                  int64_t R, int S, int per_ray, int white_background, float* rgb, float* weights,
+                                  float* depth, float* acc, void* stream) {
     NERF_REQUIRE(R >= 0 && S >= 1 && S <= 1024, "nerf_composite_fwd: bad R=%lld S=%d (1..1024)", (long long)R, S);
     if (R == 0) return NERF_OK;
     NERF_REQUIRE_PTR(colors);
@@ -293,16 +300,16 @@ extern "C" int nerf_composite_fwd(const float* colors, const float* densities, c
     NERF_REQUIRE(ceil_div64(R, kWavesPerBlock) < (1ll << 31), "nerf_composite_fwd: too many rays");
     hipStream_t st = (hipStream_t)stream;
     const int epl = (S + 63) / 64;
-    if (epl <= 1) return launch_fwd<1>(colors, densities, deltas, t, R, S, white_background, rgb, weights, depth, acc, st);
-    if (epl <= 2) return launch_fwd<2>(colors, densities, deltas, t, R, S, white_background, rgb, weights, depth, acc, st);
-    if (epl <= 4) return launch_fwd<4>(colors, densities, deltas, t, R, S, white_background, rgb, weights, depth, acc, st);
-    if (epl <= 8) return launch_fwd<8>(colors, densities, deltas, t, R, S, white_background, rgb, weights, depth, acc, st);
-    return launch_fwd<16>(colors, densities, deltas, t, R, S, white_background, rgb, weights, depth, acc, st);
+    if (epl <= 1) return launch_fwd<1>(colors, densities, deltas, t, R, S, per_ray, white_background, rgb, weights, depth, acc, st);
+    if (epl <= 2) return launch_fwd<2>(colors, densities, deltas, t, R, S, per_ray, white_background, rgb, weights, depth, acc, st);
+    if (epl <= 4) return launch_fwd<4>(colors, densities, deltas, t, R, S, per_ray, white_background, rgb, weights, depth, acc, st);
+    if (epl <= 8) return launch_fwd<8>(colors, densities, deltas, t, R, S, per_ray, white_background, rgb, weights, depth, acc, st);
+    return launch_fwd<16>(colors, densities, deltas, t, R, S, per_ray, white_background, rgb, weights, depth, acc, st);
 }
 
 extern "C" int nerf_composite_bwd(const float* colors, const float* densities, const float* deltas, int64_t R, int S,
-                                  int white_background, const float* grad_rgb, float* dcolors, float* ddensities,
-                                  void* stream) {
+                                  int per_ray, int white_background, const float* grad_rgb, float* dcolors,
+                                  float* ddensities, void* stream) {
     NERF_REQUIRE(R >= 0 && S >= 1 && S <= 1024, "nerf_composite_bwd: bad R=%lld S=%d (1..1024)", (long long)R, S);
     if (R == 0) return NERF_OK;
     NERF_REQUIRE_PTR(colors);
@@ -314,11 +321,11 @@ extern "C" int nerf_composite_bwd(const float* colors, const float* densities, c
     NERF_REQUIRE(ceil_div64(R, kWavesPerBlock) < (1ll << 31), "nerf_composite_bwd: too many rays");
     hipStream_t st = (hipStream_t)stream;
     const int epl = (S + 63) / 64;
-    if (epl <= 1) return launch_bwd<1>(colors, densities, deltas, R, S, white_background, grad_rgb, dcolors, ddensities, st);
-    if (epl <= 2) return launch_bwd<2>(colors, densities, deltas, R, S, white_background, grad_rgb, dcolors, ddensities, st);
-    if (epl <= 4) return launch_bwd<4>(colors, densities, deltas, R, S, white_background, grad_rgb, dcolors, ddensities, st);
-    if (epl <= 8) return launch_bwd<8>(colors, densities, deltas, R, S, white_background, grad_rgb, dcolors, ddensities, st);
-    return launch_bwd<16>(colors, densities, deltas, R, S, white_background, grad_rgb, dcolors, ddensities, st);
+    if (epl <= 1) return launch_bwd<1>(colors, densities, deltas, R, S, per_ray, white_background, grad_rgb, dcolors, ddensities, st);
+    if (epl <= 2) return launch_bwd<2>(colors, densities, deltas, R, S, per_ray, white_background, grad_rgb, dcolors, ddensities, st);
+    if (epl <= 4) return launch_bwd<4>(colors, densities, deltas, R, S, per_ray, white_background, grad_rgb, dcolors, ddensities, st);
+    if (epl <= 8) return launch_bwd<8>(colors, densities, deltas, R, S, per_ray, white_background, grad_rgb, dcolors, ddensities, st);
+    return launch_bwd<16>(colors, densities, deltas, R, S, per_ray, white_background, grad_rgb, dcolors, ddensities, st);
 }
 
 extern "C" int nerf_exclusive_cumprod(const float* betas, int64_t R, int S, float* out, void* stream) {

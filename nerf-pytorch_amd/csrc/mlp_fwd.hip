@@ -150,6 +150,7 @@ struct FwdArgs {
     const float* rays_d;
     const float* t;
     int S;
+    int t_per_ray;
     float nearf, spanf;
     float* colors;
     float* density;
@@ -180,7 +181,7 @@ __device__ __forceinline__ void load_inputs(const FwdArgs& a, size_t m0, float* 
                 for (int c = 0; c < 3; ++c) { x[c] = a.points[m * 3 + c]; d[c] = a.dirs[m * 3 + c]; }
             } else {
                 const size_t r = m / (size_t)a.S;
-                const float ts = a.t[m - r * (size_t)a.S];
+                const float ts = a.t_per_ray ? a.t[m] : a.t[m - r * (size_t)a.S];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     d[c] = a.rays_d[r * 3 + c];
@@ -482,8 +483,8 @@ int set_lds(K kernel, int bytes) {
 }  // namespace
 
 extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const float* points, const float* dirs,
-                            const float* rays_o, const float* rays_d, const float* t, int S, double near, double far,
-                            float* colors, float* density, float* workspace, void* stream) {
+                            const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near,
+                            double far, float* colors, float* density, float* workspace, void* stream) {
     NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "nerf_mlp_fwd: unknown model %d", model);
     NERF_REQUIRE(M >= 0, "nerf_mlp_fwd: M=%lld < 0", (long long)M);
     if (M == 0) return NERF_OK;
@@ -502,7 +503,7 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
     const size_t mp = lay::padded_samples(M);
     const size_t tiles = mp / lay::TILE;
     NERF_REQUIRE(tiles < (1ull << 31), "nerf_mlp_fwd: too many samples");
-    FwdArgs a{packed, M, mp, points, dirs, rays_o, rays_d, t, S, (float)near, (float)(far - near), colors, density, workspace};
+    FwdArgs a{packed, M, mp, points, dirs, rays_o, rays_d, t, S, t_per_ray, (float)near, (float)(far - near), colors, density, workspace};
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (model == NERF_MODEL_NERF) {

@@ -259,3 +259,55 @@ extern "C" int nerf_compute_rays(const float* c2w, int64_t N, int H, int W, doub
                                                                                         rays_o, rays_d);
     return nerf_check_launch("nerf_compute_rays");
 }
+
+// ---------------------------------------------------------------------------------------
+// sorted union of the shared coarse depths and each ray's fine depths (canonical NeRF:
+// sort(cat(z_vals, z_samples))) plus the successive differences the compositor needs.
+// One ray per wavefront, bitonic sort of the padded (+inf) sequence in LDS.
+// ---------------------------------------------------------------------------------------
+#define MERGE_MAX 1024
+__global__ __launch_bounds__(256) void merge_samples_kernel(const float* __restrict__ tc, const float* __restrict__ tf,
+                                                           int64_t R, int Sc, int Sf, int N, float* __restrict__ t_all,
+                                                           float* __restrict__ deltas) {
+    __shared__ float buf[4][MERGE_MAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t rr = r < R ? r : R - 1;  // out-of-range waves redo the last ray and store nothing
+    float* b = buf[wv];
+    const int S = Sc + Sf;
+    for (int i = lane; i < N; i += 64) b[i] = i < Sc ? tc[i] : (i < S ? tf[rr * Sf + (i - Sc)] : INFINITY);
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < N; i += 64) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float x = b[i], y = b[p];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { b[i] = y; b[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    if (r < R)
+        for (int i = lane; i < S; i += 64) {
+            t_all[r * S + i] = b[i];
+            deltas[r * S + i] = (i + 1 < S) ? sub_rn(b[i + 1], b[i]) : 1e10f;
+        }
+}
+
+extern "C" int nerf_merge_samples(const float* t_coarse, const float* t_fine, int64_t R, int Sc, int Sf, float* t_all,
+                                  float* deltas, void* stream) {
+    NERF_REQUIRE(R >= 0 && Sc >= 1 && Sf >= 0 && Sc + Sf <= MERGE_MAX, "nerf_merge_samples: bad R=%lld Sc=%d Sf=%d",
+                 (long long)R, Sc, Sf);
+    if (R == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(t_coarse);
+    if (Sf > 0) NERF_REQUIRE_PTR(t_fine);
+    NERF_REQUIRE_PTR(t_all);
+    NERF_REQUIRE_PTR(deltas);
+    int N = 2;
+    while (N < Sc + Sf) N <<= 1;
+    merge_samples_kernel<<<(unsigned)ceil_div64(R, 4), 256, 0, (hipStream_t)stream>>>(t_coarse, t_fine, R, Sc, Sf, N,
+                                                                                     t_all, deltas);
+    return nerf_check_launch("nerf_merge_samples");
+}

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 MODEL_NERF = 0
 MODEL_SIREN = 1
 NUM_PARAM_TENSORS = 24
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -37,14 +37,15 @@ _SIGS = {
     "nerf_compute_rays": (c_int, [_P, c_int64, c_int, c_int, c_double, _P, _P, _P]),
     "nerf_exclusive_cumprod": (c_int, [_P, c_int64, c_int, _P, _P]),
     "nerf_posenc_fwd": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
-    "nerf_composite_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
-    "nerf_composite_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "nerf_composite_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "nerf_composite_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
     "nerf_mlp_param_floats": (c_size_t, [c_int]),
     "nerf_mlp_packed_floats": (c_size_t, [c_int]),
     "nerf_mlp_fwd_workspace_floats": (c_size_t, [c_int, c_int64]),
     "nerf_mlp_bwd_workspace_floats": (c_size_t, [c_int, c_int64]),
     "nerf_mlp_pack": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
-    "nerf_mlp_fwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_double, c_double, _P, _P, _P, _P]),
+    "nerf_mlp_fwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P, _P, _P, _P]),
+    "nerf_merge_samples": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "nerf_mlp_bwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "nerf_mlp_bwd_data": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "nerf_mlp_bwd_weights": (c_int, [c_int, c_int64, _P, _P, _P, _P]),
@@ -176,7 +177,9 @@ def posenc(x: torch.Tensor, L: int) -> torch.Tensor:
 def composite_fwd(colors, densities, deltas, white: bool, t=None, want_weights=False, want_depth=False,
                   want_acc=False):
     R, S = densities.shape
-    if colors.shape != (R, S, 3) or deltas.shape != (S,):
+    per_ray = deltas.dim() == 2
+    if colors.shape != (R, S, 3) or deltas.shape != ((R, S) if per_ray else (S,)) or \
+            (t is not None and t.shape != deltas.shape):
         raise ValueError(f"composite: colors {tuple(colors.shape)} densities {tuple(densities.shape)} "
                          f"deltas {tuple(deltas.shape)} do not agree")
     dev = densities.device
@@ -187,7 +190,7 @@ def composite_fwd(colors, densities, deltas, white: bool, t=None, want_weights=F
     if want_depth and t is None:
         raise ValueError("depth output needs t")
     _check(lib.nerf_composite_fwd(_dev(colors, "colors"), _dev(densities, "densities"), _dev(deltas, "deltas"),
-                                  _opt(t, "t"), R, S, int(bool(white)), _dev(rgb, "rgb"), _opt(weights, "weights"),
+                                  _opt(t, "t"), R, S, int(per_ray), int(bool(white)), _dev(rgb, "rgb"), _opt(weights, "weights"),
                                   _opt(depth, "depth"), _opt(acc, "acc"), _stream()), "nerf_composite_fwd")
     return rgb, weights, depth, acc
 
@@ -197,7 +200,7 @@ def composite_bwd(colors, densities, deltas, white: bool, grad_rgb):
     dcolors = torch.empty_like(colors)
     ddens = torch.empty_like(densities)
     _check(lib.nerf_composite_bwd(_dev(colors, "colors"), _dev(densities, "densities"), _dev(deltas, "deltas"), R, S,
-                                  int(bool(white)), _dev(grad_rgb, "grad_rgb"), _dev(dcolors, "dcolors"),
+                                  int(deltas.dim() == 2), int(bool(white)), _dev(grad_rgb, "grad_rgb"), _dev(dcolors, "dcolors"),
                                   _dev(ddens, "ddensities"), _stream()), "nerf_composite_bwd")
     return dcolors, ddens
 
@@ -232,7 +235,8 @@ def mlp_fwd(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None,
         ws = torch.empty(lib.nerf_mlp_fwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
     ev = timers.start("mlp_fwd_train" if train else "mlp_fwd_infer")
     _check(lib.nerf_mlp_fwd(model, _dev(packed, "packed"), M, _opt(points, "points"), _opt(dirs, "dirs"),
-                            _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S, float(near), float(far),
+                            _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S,
+                            int(t is not None and t.dim() == 2), float(near), float(far),
                             _dev(colors, "colors"), _dev(density, "density"), _opt(ws, "workspace"), _stream()),
            "nerf_mlp_fwd")
     timers.stop(ev)
@@ -270,6 +274,17 @@ def weights_to_cdf(weights: torch.Tensor) -> torch.Tensor:
     cdf = torch.empty((R, B + 1), dtype=torch.float32, device=weights.device)
     _check(lib.nerf_weights_to_cdf(_dev(weights, "weights"), R, B, _dev(cdf, "cdf"), _stream()), "nerf_weights_to_cdf")
     return cdf
+
+
+def merge_samples(t_coarse: torch.Tensor, t_fine: torch.Tensor):
+    """Sorted union of shared coarse depths [Sc] and per-ray fine depths [R,Sf] -> (t_all, deltas) [R,Sc+Sf]."""
+    R, Sf = t_fine.shape
+    Sc = t_coarse.shape[0]
+    t_all = torch.empty((R, Sc + Sf), dtype=torch.float32, device=t_fine.device)
+    deltas = torch.empty_like(t_all)
+    _check(lib.nerf_merge_samples(_dev(t_coarse, "t_coarse"), _dev(t_fine, "t_fine"), R, Sc, Sf, _dev(t_all, "t_all"),
+                                  _dev(deltas, "deltas"), _stream()), "nerf_merge_samples")
+    return t_all, deltas
 
 
 def sample_pdf(bins: torch.Tensor, cdf: torch.Tensor, u: torch.Tensor):

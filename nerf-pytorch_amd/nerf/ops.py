@@ -95,7 +95,7 @@ class RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model_id, packed, rays_o, rays_d, t, deltas, near, far, white, want_extras, train, *params):
-        R, S = rays_o.shape[0], t.shape[0]
+        R, S = rays_o.shape[0], t.shape[-1]   # t is [S] (shared) or [R,S] (per ray)
         M = R * S
         colors, density, ws = _hip.mlp_fwd(model_id, packed, M, rays_o=rays_o, rays_d=rays_d, t=t, S=S, near=near,
                                            far=far, train=train)

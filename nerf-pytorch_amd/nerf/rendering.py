@@ -132,3 +132,58 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
     if return_extras:
         return (rgb,) + tuple(torch.cat([e[k] for e in extras], dim=0) for k in range(3))
     return rgb
+
+
+def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, rays_o: Tensor, rays_d: Tensor,
+                             near: float, far: float, num_coarse: int = 64, num_fine: int = 128,
+                             device: str = 'cuda', white_background: bool = True, chunk_size: int = 8192, *,
+                             u: Optional[Sequence[Tensor]] = None, u_fine: Optional[Sequence[Tensor]] = None,
+                             return_extras: bool = False):
+    """Coarse + fine rendering with inverse-CDF re-sampling.  NOT in the reference (its renderer is
+    single pass, rendering.py:156-226); this follows the published NeRF procedure: a stratified
+    coarse pass, a per-ray PDF from the interior coarse weights over the mid-points of the coarse
+    depths, `num_fine` inverse-CDF samples per ray (no gradient through the sampling), and a fine pass
+    over the sorted union (num_coarse + num_fine evaluations per ray).
+
+    Returns (rgb_coarse [N,3], rgb_fine [N,3]) -- train on the sum of both MSEs -- plus, with
+    return_extras, the fine pass's (weights [N,S], depth [N], acc [N]).  `u[ci]` [num_coarse] and
+    `u_fine[ci]` [rays_in_chunk, num_fine] override the random draws of chunk ci.
+    """
+    rays_o = _f32c(rays_o.to(device))
+    rays_d = _f32c(rays_d.to(device))
+    if not rays_o.is_cuda:
+        raise RuntimeError("render_nerf_hierarchical: this build has no CPU path; pass device='cuda'")
+    if num_coarse < 3:
+        raise ValueError("num_coarse must be at least 3 (the PDF is built from interior coarse samples)")
+    for m in (coarse, fine):
+        if not _fused_model(m):
+            raise TypeError("render_nerf_hierarchical needs this package's NeRF/Siren modules")
+        m._check_supported()
+    pc, pf = coarse.ordered_parameters(), fine.ordered_parameters()
+    wc, wf = coarse.packed_weights(), fine.packed_weights()
+    tc_train, tf_train = wants_grad(pc), wants_grad(pf)
+    out_c, out_f, extras = [], [], []
+    for ci, i in enumerate(range(0, rays_o.shape[0], chunk_size)):
+        o, d = rays_o[i:i + chunk_size], rays_d[i:i + chunk_size]
+        R = o.shape[0]
+        t_c, deltas_c = _t_and_deltas(near, far, num_coarse, rays_o.device, None if u is None else u[ci].to(rays_o.device))
+        rgb_c, w_c, _, _ = RenderFunction.apply(coarse.model_id, wc, o, d, t_c, deltas_c, float(near), float(far),
+                                                bool(white_background), True, tc_train, *pc)
+        with torch.no_grad():
+            t_mid = (0.5 * (t_c[1:] + t_c[:-1])).expand(R, -1).contiguous()          # [R, Nc-1] bin edges
+            cdf = _hip.weights_to_cdf(w_c[:, 1:-1].contiguous())                      # [R, Nc-1]
+            uf = torch.rand(R, num_fine, device=rays_o.device) if u_fine is None else _f32c(u_fine[ci].to(rays_o.device))
+            t_f, _ = _hip.sample_pdf(t_mid, cdf, uf)
+            t_all, deltas_all = _hip.merge_samples(t_c, t_f)
+        res = RenderFunction.apply(fine.model_id, wf, o, d, t_all, deltas_all, float(near), float(far),
+                                   bool(white_background), bool(return_extras), tf_train, *pf)
+        out_c.append(rgb_c)
+        if return_extras:
+            out_f.append(res[0])
+            extras.append(res[1:])
+        else:
+            out_f.append(res)
+    rgb_c, rgb_f = torch.cat(out_c, dim=0), torch.cat(out_f, dim=0)
+    if return_extras:
+        return (rgb_c, rgb_f) + tuple(torch.cat([e[k] for e in extras], dim=0) for k in range(3))
+    return rgb_c, rgb_f

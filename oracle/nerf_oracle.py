@@ -372,6 +372,38 @@ def sample_pdf(bins: Tensor, weights: Tensor, u: Tensor) -> Tuple[Tensor, Tensor
     return b0 + (u - c0) / den * (b1 - b0), idx
 
 
+def render_hierarchical(coarse_fn, fine_fn, rays_o: Tensor, rays_d: Tensor, near: float, far: float,
+                        num_coarse: int, num_fine: int, u_coarse: Tensor, u_fine: Tensor,
+                        white_background: bool = True):
+    """Coarse + fine render of the published NeRF (run_nerf.render_rays), restated on top of
+    this file's single-pass pieces.  PARITY UNPINNED: the reference has no such path.
+    u_coarse [Nc], u_fine [R,Nf].  Returns rgb_coarse, rgb_fine, weights_fine, t_all."""
+    R = rays_o.shape[0]
+    t_c = stratified_t(near, far, num_coarse, u_coarse)
+
+    def run(fn, t_rays, deltas_rays):
+        S = t_rays.shape[1]
+        pos = rays_o[:, None, :] + t_rays[:, :, None] * rays_d[:, None, :]
+        dirs = rays_d[:, None, :].expand(-1, S, -1).reshape(-1, 3)
+        col, den = fn(normalize_positions(pos.reshape(-1, 3), near, far), dirs)
+        col, den = col.reshape(R, S, 3), den.reshape(R, S)
+        alpha = 1 - torch.exp(-den * deltas_rays)
+        w = exclusive_transmittance(1 - alpha) * alpha
+        rgb = (w[..., None] * col).sum(1)
+        if white_background:
+            rgb = rgb + (1 - w.sum(1, keepdim=True))
+        return rgb, w
+
+    d_c = sample_deltas(t_c)
+    rgb_c, w_c = run(coarse_fn, t_c[None].expand(R, -1), d_c[None].expand(R, -1))
+    t_mid = 0.5 * (t_c[1:] + t_c[:-1])
+    t_f, _ = sample_pdf(t_mid[None].expand(R, -1).contiguous(), w_c[:, 1:-1].detach(), u_fine)
+    t_all, _ = torch.sort(torch.cat([t_c[None].expand(R, -1), t_f.detach()], dim=1), dim=1)
+    d_all = torch.cat([t_all[:, 1:] - t_all[:, :-1], torch.full((R, 1), 1e10)], dim=1)
+    rgb_f, w_f = run(fine_fn, t_all, d_all)
+    return rgb_c, rgb_f, w_f, t_all
+
+
 # ----------------------------------------------------------------------------
 # train step (train.py:123-131, 166-183)
 # ----------------------------------------------------------------------------

@@ -440,3 +440,94 @@ def test_sample_pdf_indices_bit_exact(hip):
     assert (s.cpu() - s_ref).abs().max() <= 1e-5
     cdf_gpu = hip.weights_to_cdf(w.to(DEV))
     assert (cdf_gpu.cpu() - cdf).abs().max() <= 2e-6
+
+
+def test_merge_samples_sorted_union(hip):
+    g = torch.Generator().manual_seed(8)
+    for R, Sc, Sf in [(130, 64, 128), (5, 7, 0 + 3), (33, 100, 411), (4, 512, 512)]:
+        t_c = O.stratified_t(2.0, 6.0, Sc, torch.rand(Sc, generator=g))
+        t_f = torch.rand(R, Sf, generator=g) * 4 + 2
+        t_all, deltas = hip.merge_samples(t_c.to(DEV), t_f.to(DEV))
+        ref, _ = torch.sort(torch.cat([t_c[None].expand(R, -1), t_f], dim=1), dim=1)
+        assert torch.equal(t_all.cpu(), ref)
+        dref = torch.cat([ref[:, 1:] - ref[:, :-1], torch.full((R, 1), 1e10)], dim=1)
+        assert torch.equal(deltas.cpu(), dref)
+
+
+@pytest.mark.parametrize("S", [64, 192, 256])
+def test_composite_per_ray_depths(hip, S):
+    g = torch.Generator().manual_seed(S + 1)
+    R = 77
+    t, _ = torch.sort(torch.rand(R, S, generator=g) * 4 + 2, dim=1)
+    deltas = torch.cat([t[:, 1:] - t[:, :-1], torch.full((R, 1), 1e10)], dim=1)
+    dens = torch.relu(torch.randn(R, S, generator=g)) * 10
+    cols = torch.rand(R, S, 3, generator=g)
+    gr = torch.randn(R, 3, generator=g)
+    c, s = cols.clone().requires_grad_(True), dens.clone().requires_grad_(True)
+    alpha = 1 - torch.exp(-s * deltas)
+    w = O.exclusive_transmittance(1 - alpha) * alpha
+    ref = (w[..., None] * c).sum(1) + (1 - w.sum(1, keepdim=True))
+    (ref * gr).sum().backward()
+    rgb, wg, depth, acc = hip.composite_fwd(cols.to(DEV), dens.to(DEV), deltas.to(DEV), True, t=t.to(DEV),
+                                            want_weights=True, want_depth=True, want_acc=True)
+    dc, ds = hip.composite_bwd(cols.to(DEV), dens.to(DEV), deltas.to(DEV), True, gr.to(DEV))
+    assert rel(rgb, ref) < RTOL and rel(wg, w) < RTOL and rel(depth, (w * t).sum(1)) < RTOL
+    assert rel(dc, c.grad) < RTOL and rel(ds, s.grad) < RTOL
+
+
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
+def test_hierarchical_render_vs_oracle(tag):
+    """Coarse + fine path (no counterpart in the reference: parity unpinned, checked against the
+    canonical-NeRF restatement in the oracle).  The inverse-CDF step is discontinuous in the
+    coarse weights (a last-bit CDF difference can move a sample to the neighbouring bin), so the
+    fine image is compared at 2e-4 relative; the coarse image and its gradients at 1e-5."""
+    from nerf.rendering import render_nerf_hierarchical
+    coarse, pc = make_model(tag)
+    fine, pf = make_model(tag)
+    with torch.no_grad():   # a different fine network
+        for p in fine.parameters():
+            p.mul_(0.97)
+        pf = {k: v * 0.97 for k, v in pf.items()}
+    R, Nc, Nf = 96, 64, 128
+    o, d = rays(R, 41)
+    g = torch.Generator().manual_seed(42)
+    u_c, u_f = torch.rand(Nc, generator=g), torch.rand(R, Nf, generator=g)
+    tgt = torch.rand(R, 3, generator=g)
+    fwd = oracle_fwd(tag)
+    for p in list(pc.values()) + list(pf.values()):
+        p.requires_grad_(True)
+    rc, rf, w_f, t_all = O.render_hierarchical(lambda x, v: fwd(pc, x, v), lambda x, v: fwd(pf, x, v), o, d, 2.0, 6.0,
+                                               Nc, Nf, u_c, u_f)
+    loss_ref = torch.nn.functional.mse_loss(rc, tgt) + torch.nn.functional.mse_loss(rf, tgt)
+    gc_ref = torch.autograd.grad(loss_ref, list(pc.values()) + list(pf.values()), retain_graph=True)
+    rgb_c, rgb_f, w, depth, acc = render_nerf_hierarchical(coarse, fine, o, d, 2.0, 6.0, Nc, Nf, device=DEV,
+                                                           u=[u_c.to(DEV)], u_fine=[u_f.to(DEV)], return_extras=True)
+    assert rgb_c.shape == (R, 3) and rgb_f.shape == (R, 3) and w.shape == (R, Nc + Nf)
+    assert rel(rgb_c, rc) < RTOL
+    assert rel(rgb_f, rf) < 2e-4
+    loss = torch.nn.functional.mse_loss(rgb_c, tgt.to(DEV)) + torch.nn.functional.mse_loss(rgb_f, tgt.to(DEV))
+    loss.backward()
+    n_c = len(pc)
+    # 6144 coarse samples x 2432 ReLU units: a handful of pre-activations sit within rounding of
+    # zero and flip (see test_model_ragged_sizes_full_gradients), hence the looser NeRF bound here;
+    # the sine network has no kinks in its hidden layers
+    ctol = 1e-3 if tag == "nerf" else 3 * RTOL
+    for (n, p), gr in zip(coarse.named_parameters(), gc_ref[:n_c]):
+        assert rel(p.grad, gr) < ctol, (n, rel(p.grad, gr))
+    # end to end the fine gradients inherit the bin flips of the re-sampling: sanity bound only
+    for (n, p), gr in zip(fine.named_parameters(), gc_ref[n_c:]):
+        assert rel(p.grad, gr) < 2e-2, (n, rel(p.grad, gr))
+    assert float(acc.max()) <= 1 + 1e-5 and float(depth.min()) >= 0
+
+    # the fine pass on its own, fed the ORACLE's per-ray depths: tight again
+    from nerf.ops import RenderFunction
+    fine.zero_grad(set_to_none=True)
+    t_all = t_all.contiguous()
+    d_all = torch.cat([t_all[:, 1:] - t_all[:, :-1], torch.full((R, 1), 1e10)], dim=1)
+    rgb_f2 = RenderFunction.apply(fine.model_id, fine.packed_weights(), o.to(DEV), d.to(DEV), t_all.to(DEV),
+                                  d_all.to(DEV), 2.0, 6.0, True, False, True, *fine.ordered_parameters())
+    assert rel(rgb_f2, rf) < RTOL
+    torch.nn.functional.mse_loss(rgb_f2, tgt.to(DEV)).backward()
+    gf_ref = torch.autograd.grad(torch.nn.functional.mse_loss(rf, tgt), list(pf.values()))
+    for (n, p), gr in zip(fine.named_parameters(), gf_ref):
+        assert rel(p.grad, gr) < ctol, (n, rel(p.grad, gr))

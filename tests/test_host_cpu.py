@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_hip.lib, s), f"libnerf_hip.so does not export {s}"
         assert s in _hip.EXPORTS, f"{s} declared in nerf_hip.h but not bound in nerf/_hip.py"
-    assert _hip.lib.nerf_abi_version() == 1
+    assert _hip.lib.nerf_abi_version() == 2
 
 
 def test_sizes_match_reference_parameter_counts():
@@ -49,12 +49,12 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.nerf_stratified_t(2.0, 6.0, 0, None, None, None, None) == -1
     assert b"S=0" in lib.nerf_last_error()
     assert lib.nerf_stratified_t(2.0, 6.0, 8, None, None, None, None) == -2
-    assert lib.nerf_composite_fwd(None, None, None, None, 4, 2000, 1, None, None, None, None, None) == -1
-    assert lib.nerf_mlp_fwd(5, None, 10, None, None, None, None, None, 0, 0.0, 1.0, None, None, None, None) == -1
+    assert lib.nerf_composite_fwd(None, None, None, None, 4, 2000, 0, 1, None, None, None, None, None) == -1
+    assert lib.nerf_mlp_fwd(5, None, 10, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None, None) == -1
     assert lib.nerf_posenc_fwd(None, 10, 9, 4, None, None) == -1
     assert lib.nerf_mlp_pack(0, None, None, None) == -2
     # zero-sized work is a no-op that needs no pointers
-    assert lib.nerf_composite_fwd(None, None, None, None, 0, 64, 1, None, None, None, None, None) == 0
+    assert lib.nerf_composite_fwd(None, None, None, None, 0, 64, 0, 1, None, None, None, None, None) == 0
     assert lib.nerf_sample_positions(None, None, None, 0, 64, 0, 2.0, 6.0, None, None) == 0
 
 
