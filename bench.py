@@ -36,6 +36,13 @@ FLOPS = {
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per MLP evaluation from the committed rocprofv3 --pmc passes (profiles/r1_pmc_fetch.csv,
+# r1_pmc_write.csv: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch / 1,048,576 samples; FETCH_SIZE
+# doubled as the gfx950 note on wide coalesced reads prescribes).  Counters cannot be read from
+# inside this process, so these are constants of the measured build, per sample.
+TRAFFIC_BYTES_PER_SAMPLE = {
+    ("nerf", "mlp_fwd_train"): (2 * 691936 + 11420000) * 1024 / 1048576,   # 12.5 KB: 11.1 KB activations written
+}
 
 
 def make_rays(n_views, H, W, device, seed=42):
@@ -72,7 +79,7 @@ def _pose_spherical(theta, phi, radius):
     return (swap @ (ry @ (rx @ t))).astype(np.float32)
 
 
-def cpu_baseline(model_name, rays, samples, steps=2):
+def cpu_baseline(model_name, rays, samples, hier=False, n_coarse=64, n_fine=128, steps=2):
     """The CPU restatement (oracle) timed on the host cores: same step (render, MSE, backward,
     Adam) on a bounded sample of the same workload."""
     from oracle import nerf_oracle as O
@@ -80,28 +87,35 @@ def cpu_baseline(model_name, rays, samples, steps=2):
     is_nerf = model_name == "nerf"
     shapes = O.nerf_param_shapes() if is_nerf else O.siren_param_shapes()
     params = O.closed_form_params(shapes, gains=None if is_nerf else O.SIREN_GAINS)
-    for p in params.values():
+    params2 = {k: v.clone() for k, v in params.items()}
+    for p in list(params.values()) + list(params2.values()):
         p.requires_grad_(True)
     fwd = O.nerf_forward if is_nerf else O.siren_forward
     o = torch.randn(rays, 3); o = 4 * o / o.norm(dim=1, keepdim=True)
     d = -o / 4 + 0.1 * torch.randn(rays, 3); d = d / d.norm(dim=1, keepdim=True)
     target = torch.rand(rays, 3)
-    m = {n: torch.zeros_like(p) for n, p in params.items()}
-    v = {n: torch.zeros_like(p) for n, p in params.items()}
+    allp = list(params.values()) + (list(params2.values()) if hier else [])
+    m = [torch.zeros_like(p) for p in allp]
+    v = [torch.zeros_like(p) for p in allp]
     times = []
     for it in range(steps + 1):
         t0 = time.perf_counter()
-        rgb = O.render(lambda x, dd: fwd(params, x, dd), o, d, 2.0, 6.0, samples, [torch.rand(samples)])
-        loss = torch.nn.functional.mse_loss(rgb, target)
-        grads = torch.autograd.grad(loss, list(params.values()))
+        if hier:
+            rc, rf, _, _ = O.render_hierarchical(lambda x, dd: fwd(params, x, dd), lambda x, dd: fwd(params2, x, dd), o, d,
+                                                 2.0, 6.0, n_coarse, n_fine, torch.rand(n_coarse), torch.rand(rays, n_fine))
+            loss = torch.nn.functional.mse_loss(rc, target) + torch.nn.functional.mse_loss(rf, target)
+        else:
+            rgb = O.render(lambda x, dd: fwd(params, x, dd), o, d, 2.0, 6.0, samples, [torch.rand(samples)])
+            loss = torch.nn.functional.mse_loss(rgb, target)
+        grads = torch.autograd.grad(loss, allp)
         with torch.no_grad():
-            for (n, p), g in zip(params.items(), grads):
-                O.adam_step(p, g, m[n], v[n], it + 1, 5e-4)
+            for i, (p, g) in enumerate(zip(allp, grads)):
+                O.adam_step(p, g, m[i], v[i], it + 1, 5e-4)
         times.append(time.perf_counter() - t0)
     best = float(np.median(times[1:]))
     return {"value": rays / best, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{rays} rays x {samples} samples, {model_name}, fwd+bwd+Adam, median of {steps} steps after 1 warm-up "
-                      f"(oracle/nerf_oracle.py, torch CPU fp32)"}
+            "sample": f"{rays} rays x {samples} MLP evaluations/ray ({'coarse+fine' if hier else 'single pass'}), {model_name}, "
+                      f"fwd+bwd+Adam, median of {steps} steps after 1 warm-up (oracle/nerf_oracle.py, torch CPU fp32)"}
 
 
 def main():
@@ -115,6 +129,11 @@ def main():
     ap.add_argument("--views", type=int, default=100)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--sampling", default="hier", choices=["hier", "single"],
+                    help="hier: 64 coarse + (64+128) fine evaluations per ray through two networks (the metric's "
+                         "'64+128 samples/ray'); single: the reference's own single pass of --samples (config_lego.txt:15)")
+    ap.add_argument("--coarse", type=int, default=64)
+    ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     args = ap.parse_args()
@@ -133,15 +152,20 @@ def main():
 
     from nerf import _hip, parallel
     from nerf.models import NeRF, Siren
-    from nerf.rendering import render_nerf
+    from nerf.rendering import render_nerf, render_nerf_hierarchical
 
     torch.manual_seed(42)
     np.random.seed(42)
-    model = (NeRF() if args.model == "nerf" else Siren()).to(dev)
-    flat = parallel.FlatParameters(model)
-    flat.broadcast_parameters(0)
-    opt = parallel.FusedAdam(flat, lr=5e-4)
-    near, far, S, B = 2.0, 6.0, args.samples, args.rays
+    hier = args.sampling == "hier"
+    Model = NeRF if args.model == "nerf" else Siren
+    models = [Model().to(dev) for _ in range(2 if hier else 1)]   # [coarse, fine] or [single]
+    model = models[0]
+    flats = [parallel.FlatParameters(m) for m in models]
+    for f in flats:
+        f.broadcast_parameters(0)
+    opts = [parallel.FusedAdam(f, lr=5e-4) for f in flats]
+    near, far, B = 2.0, 6.0, args.rays
+    S = args.coarse + (args.coarse + args.fine) if hier else args.samples     # MLP evaluations per ray
 
     # ray pool resident in HBM; ranks own disjoint view ranges of the same scene
     views_per_rank = max(1, min(args.views // max(world, 1), 12))
@@ -150,25 +174,34 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     ugen = torch.Generator(device=dev).manual_seed(999)  # same seed on all ranks; also broadcast
 
+    def render(o, d):
+        if hier:
+            u = parallel.shared_uniform(args.coarse, dev, ugen)
+            rc, rf = render_nerf_hierarchical(models[0], models[1], o, d, near, far, args.coarse, args.fine, device=dev,
+                                              white_background=True, chunk_size=max(B, 8192), u=[u])
+            return rc, rf
+        u = parallel.shared_uniform(S, dev, ugen)
+        return (render_nerf(model, o, d, near, far, num_samples=S, device=dev, white_background=True,
+                            chunk_size=max(B, 8192), u=[u]),)
+
     def train_step(step):
         idx = torch.randint(0, n_pool, (B,), device=dev, generator=gen)
         o, d, tgt = rays_o[idx], rays_d[idx], target[idx]
-        u = parallel.shared_uniform(S, dev, ugen)
-        pred = render_nerf(model, o, d, near, far, num_samples=S, device=dev, white_background=True,
-                           chunk_size=max(B, 8192), u=[u])
-        opt.zero_grad()
-        loss = torch.nn.functional.mse_loss(pred, tgt)
+        preds = render(o, d)
+        for opt in opts:
+            opt.zero_grad()
+        loss = sum(torch.nn.functional.mse_loss(p, tgt) for p in preds)
         loss.backward()
-        flat.all_reduce_mean()
-        opt.lr = opt.base_lr * parallel.lr_lambda(step, opt.base_lr, 300.0, 0.1, 1e-4)
-        opt.step()
+        for f, opt in zip(flats, opts):
+            f.all_reduce_mean()
+            opt.lr = opt.base_lr * parallel.lr_lambda(step, opt.base_lr, 300.0, 0.1, 1e-4)
+            opt.step()
         return loss
 
     def infer_step(step):
         idx = torch.randint(0, n_pool, (B,), device=dev, generator=gen)
         with torch.no_grad():
-            return render_nerf(model, rays_o[idx], rays_d[idx], near, far, num_samples=S, device=dev,
-                               white_background=True, chunk_size=max(B, 8192))
+            return render(rays_o[idx], rays_d[idx])[-1]
 
     step_fn = train_step if args.mode == "train" else infer_step
 
@@ -195,38 +228,52 @@ def main():
     final = float(out.float().mean().item())
 
     if rank == 0:
-        M = B * S
         fl = FLOPS[args.model]
         tm = _hip.timers.summary()
         kernels = {}
         if args.mode == "train":
-            specs = [("mlp_fwd_train", fl["fwd"] * M, "fused sample+encode+MLP forward (training, stores activations)"),
-                     ("mlp_bwd_data", fl["dgrad"] * M, "fused data-gradient chain"),
-                     ("mlp_bwd_weights", fl["wgrad"] * M, "per-layer weight-gradient GEMMs + reductions (launch group)")]
+            specs = [("mlp_fwd_train", fl["fwd"], "fused sample+encode+MLP forward (training, stores activations)"),
+                     ("mlp_bwd_data", fl["dgrad"], "fused data-gradient chain"),
+                     ("mlp_bwd_weights", fl["wgrad"], "per-layer weight-gradient GEMMs + reductions (launch group)")]
         else:
-            specs = [("mlp_fwd_infer", fl["fwd"] * M, "fused sample+encode+MLP forward (inference)")]
-        for name, flop, desc in specs:
+            specs = [("mlp_fwd_infer", fl["fwd"], "fused sample+encode+MLP forward (inference)")]
+        for name, flop_per_sample, desc in specs:
             if name in tm:
-                n, ms = tm[name]
-                kernels[name] = {"ms": ms, "tflops": flop / ms / 1e9, "flop_per_launch": flop, "what": desc}
-        dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
+                n, ms_total, samples = tm[name]
+                flop_total = flop_per_sample * samples
+                kernels[name] = {"launches_per_step": n / args.steps, "ms_per_step": ms_total / args.steps,
+                                 "ms_per_launch": ms_total / n, "flop_per_launch": flop_total / n,
+                                 "tflops": flop_total / ms_total / 1e9, "what": desc}
+        # the roofline object describes ONE kernel: the slower of the two fused single-launch kernels
+        # (the weight-gradient entry is a group of ~30 launches and stays in "kernels")
+        single = [k for k in kernels if k != "mlp_bwd_weights"]
+        dom = max(single, key=lambda k: kernels[k]["ms_per_step"]) if single else None
         roof = None
         if dom:
             ach = kernels[dom]["tflops"]
+            per_sample = dict((n_, f_) for n_, f_, _ in specs)[dom]
+            samples_per_launch = kernels[dom]["flop_per_launch"] / per_sample
+            tb = TRAFFIC_BYTES_PER_SAMPLE.get((args.model, dom))
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "ms_per_launch": kernels[dom]["ms"],
-                    "flop_per_launch": kernels[dom]["flop_per_launch"]}
-        total_flop = sum(k["flop_per_launch"] for k in kernels.values())
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": tb * samples_per_launch if tb else None,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc passes of this build, profiles/)",
+                    "ms_per_launch": kernels[dom]["ms_per_launch"], "flop_per_launch": kernels[dom]["flop_per_launch"],
+                    "flop_per_sample": per_sample, "samples_per_launch": samples_per_launch}
+        total_flop = sum(k["flop_per_launch"] * k["launches_per_step"] for k in kernels.values())
         ms_step = elapsed / args.steps * 1e3
         res = {
-            "metric": "train rays/sec (fwd+bwd+Adam, 256 MLP samples/ray)" if args.mode == "train"
-                      else "inference rays/sec (256 MLP samples/ray)",
+            "metric": (f"train rays/sec (fwd+bwd+Adam, {args.coarse}+{args.fine} samples/ray)" if hier else
+                       f"train rays/sec (fwd+bwd+Adam, {S} samples/ray single pass)") if args.mode == "train"
+                      else f"inference rays/sec ({S} MLP evaluations/ray)",
             "value": world * B * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"lego-shaped synthetic {args.res}x{args.res} scene, {B} rays/GPU/step x {S} samples/ray, "
-                                   f"{args.model} MLP (fp32 MFMA), {args.mode}", "model": args.model,
-                       "rays_per_gpu": B, "global_batch": B * world, "samples_per_ray": S,
+            "config": {"workload": f"lego-shaped synthetic {args.res}x{args.res} scene, {B} rays/GPU/step, "
+                                   + (f"{args.coarse} coarse + ({args.coarse}+{args.fine}) fine = {S} MLP evaluations/ray, "
+                                      f"coarse+fine {args.model} MLPs" if hier else
+                                      f"{S} samples/ray single pass, one {args.model} MLP")
+                                   + f" (fp32 MFMA), {args.mode}", "model": args.model, "sampling": args.sampling,
+                       "rays_per_gpu": B, "global_batch": B * world, "mlp_evals_per_ray": S,
                        "parallelism": f"dp{world} ray-sharded, flat-bucket RCCL all-reduce" if world > 1 else "single GPU"},
             "roofline": roof,
             "kernels": kernels,
@@ -234,7 +281,7 @@ def main():
             "final_value": final,
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":
-            res["cpu_baseline"] = cpu_baseline(args.model, args.cpu_rays, S)
+            res["cpu_baseline"] = cpu_baseline(args.model, args.cpu_rays, S, hier, args.coarse, args.fine)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

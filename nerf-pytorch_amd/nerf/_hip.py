@@ -98,12 +98,12 @@ class KernelTimers:
         self.enabled = False
         self.events = {}
 
-    def start(self, name):
+    def start(self, name, work=0):
         if not self.enabled:
             return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        self.events.setdefault(name, []).append((a, b))
+        self.events.setdefault(name, []).append((a, b, work))
         return b
 
     @staticmethod
@@ -112,8 +112,9 @@ class KernelTimers:
             ev.record()
 
     def summary(self):
-        """name -> (launch groups, mean ms); call after a device synchronize."""
-        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items() if v}
+        """name -> (launches, total ms, total work units); call after a device synchronize."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v), sum(w for _, _, w in v))
+                for k, v in self.events.items() if v}
 
     def reset(self):
         self.events = {}
@@ -233,7 +234,7 @@ def mlp_fwd(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None,
     ws = None
     if train:
         ws = torch.empty(lib.nerf_mlp_fwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
-    ev = timers.start("mlp_fwd_train" if train else "mlp_fwd_infer")
+    ev = timers.start("mlp_fwd_train" if train else "mlp_fwd_infer", M)
     _check(lib.nerf_mlp_fwd(model, _dev(packed, "packed"), M, _opt(points, "points"), _opt(dirs, "dirs"),
                             _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S,
                             int(t is not None and t.dim() == 2), float(near), float(far),
@@ -248,12 +249,12 @@ def mlp_bwd(model: int, packed: torch.Tensor, M: int, dcolors, ddensity, colors,
     if grads is None:
         grads = torch.empty(param_floats(model), dtype=torch.float32, device=dev)
     bw = torch.empty(lib.nerf_mlp_bwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
-    ev = timers.start("mlp_bwd_data")
+    ev = timers.start("mlp_bwd_data", M)
     _check(lib.nerf_mlp_bwd_data(model, _dev(packed, "packed"), M, _dev(dcolors, "dcolors"), _dev(ddensity, "ddensity"),
                                  _dev(colors, "colors"), _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
                                  _stream()), "nerf_mlp_bwd_data")
     timers.stop(ev)
-    ev = timers.start("mlp_bwd_weights")
+    ev = timers.start("mlp_bwd_weights", M)
     _check(lib.nerf_mlp_bwd_weights(model, M, _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
                                     _dev(grads, "grads"), _stream()), "nerf_mlp_bwd_weights")
     timers.stop(ev)
