@@ -161,19 +161,20 @@ struct WgradArgs {
     int nchunks;       // Mp / 32
     float* slab;       // [G][NW*KW]
     float* bslab;      // [G][NW] column sums of dY, or NULL
+    // RANK1 only: one more output row whose dY column q [Mp] lives apart from dY (the density row)
+    const float* q;
+    float* qslab;      // [G][KW] partials of sum_m q[m] X[m][:]
+    float* qbslab;     // [G] partials of sum_m q[m]
 };
 
 template <int NW, int KW>
-constexpr int wgrad_lds_bytes() { return 2 * 32 * (NW + KW) * 4; }
+constexpr int wgrad_lds_bytes() { return 2 * (32 * (NW + KW) + 32) * 4; }
 
-template <int NW, int KW, int WN, int WK>
+template <int NW, int KW, int WN, int WK, bool RANK1>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
     constexpr int TN = NW / WN / 32, TK = KW / WK / 32;
     constexpr int ROWF = NW + KW;             // floats per staged sample row
-    constexpr int BUF = 32 * ROWF;            // floats per buffer
-    constexpr int V4_ROW = ROWF / 4;          // 16-byte pieces per row
-    constexpr int V4_TOT = 32 * V4_ROW;
-    constexpr int NLD = (V4_TOT + 511) / 512;
+    constexpr int BUF = 32 * ROWF + 32;       // floats per buffer: dY, X, then 32 values of q
     static_assert(TN >= 1 && TK >= 1 && WN * WK <= 8, "wave layout");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -181,7 +182,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
     const int G = gridDim.x, bid = blockIdx.x;
     const int c0 = (int)((int64_t)a.nchunks * bid / G), c1 = (int)((int64_t)a.nchunks * (bid + 1) / G);
     const bool active = wave < WN * WK;
-    const bool late = active && wave >= 4;
     const int wn = wave / WK, wk = wave % WK;
     const int r = lane & 31, h = lane >> 5;
 
@@ -192,49 +192,53 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
         for (int j = 0; j < TK; ++j) acc[i][j] = splat16(0.0f);
     float bsum = 0.0f;
 
-    f32x4 stage[NLD];
-    auto gload = [&](int chunk) {
-        const size_t row0 = (size_t)chunk * 32;
+    // the next chunk goes global -> LDS directly (no staging registers, no ds_write pass).  A buffer is
+    // [32][NW] of dY followed by [32][KW] of X; 16-byte piece v of either part lands at byte 16*v of
+    // that part, which is what global_load_lds requires of a wave: a wave-uniform LDS base plus
+    // 16 bytes per lane (the per-lane SOURCE address follows the row pitch of the tensor in HBM)
+    auto stage_part = [&](const float* src, int ld, auto width, float* dst) {
+        constexpr int W4 = decltype(width)::value / 4, TOT = 32 * W4;  // TOT is a multiple of 64
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
+        for (int i = 0; i < (TOT + 511) / 512; ++i) {
             const int v = tid + i * 512;
-            if (v < V4_TOT) {
-                const int row = v / V4_ROW, c4 = v - row * V4_ROW;
-                const float* src = (c4 < NW / 4) ? a.dY + (row0 + row) * a.ldy + 4 * c4
-                                                 : a.X + (row0 + row) * a.ldx + 4 * (c4 - NW / 4);
-                stage[i] = *reinterpret_cast<const f32x4*>(src);
-            }
+            if (v < TOT)  // whole waves are in or out
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + (size_t)(v / W4) * ld + 4 * (v % W4)),
+                    (__attribute__((address_space(3))) void*)(dst + 4 * (64 * wave + i * 512)), 16, 0, 0);
         }
     };
-    auto lstore = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int v = tid + i * 512;
-            if (v < V4_TOT) *reinterpret_cast<f32x4*>(buf + 4 * v) = stage[i];
-        }
+    auto stage = [&](int chunk, float* buf) {
+        stage_part(a.dY + (size_t)chunk * 32 * a.ldy, a.ldy, std::integral_constant<int, NW>{}, buf);
+        stage_part(a.X + (size_t)chunk * 32 * a.ldx, a.ldx, std::integral_constant<int, KW>{}, buf + 32 * NW);
+        if (RANK1 && tid < 32)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.q + (size_t)chunk * 32 + tid),
+                                             (__attribute__((address_space(3))) void*)(buf + 32 * ROWF), 4, 0, 0);
     };
+    // bias column sums: all 512 threads take part, thread (grp, col) adds rows grp*BROWS.. of column col
+    constexpr int BGRP = 512 / NW, BROWS = 32 / BGRP;
+    const int bcol = tid % NW, brow0 = (tid / NW) * BROWS;
+    // rank-1 row: thread (grp, col) adds q[row] * X[row][col] over rows grp*XROWS..
+    constexpr int XGRP = 512 / KW, XROWS = 32 / XGRP;
+    const int xcol = tid % KW, xrow0 = (tid / KW) * XROWS;
+    float xsum = 0.0f, qsum = 0.0f;
 
-    if (c0 < c1) {
-        gload(c0);
-        lstore(smem);
-    }
-    __syncthreads();
+    if (c0 < c1) stage(c0, smem);
+    __syncthreads();  // also waits for the loads above (an LDS-DMA counts on vmcnt)
     for (int c = c0; c < c1; ++c) {
         const float* buf = smem + ((c - c0) & 1) * BUF;
         float* nbuf = smem + (((c - c0) & 1) ^ 1) * BUF;
-        const bool more = c + 1 < c1;
-        if (more) gload(c + 1);
+        if (c + 1 < c1) stage(c + 1, nbuf);  // nbuf was last read before the previous barrier
         if (active) {
-            const float* ap = buf + wn * (NW / WN) + r + h * ROWF;
-            const float* bp = buf + NW + wk * (KW / WK) + r + h * ROWF;
+            const float* ap = buf + wn * (NW / WN) + r + h * NW;
+            const float* bp = buf + 32 * NW + wk * (KW / WK) + r + h * KW;
             // fragments of sample pair s+1 are read from LDS before the MFMAs of pair s (two named
             // register sets, pinned): otherwise every 4-8 MFMAs wait for an LDS round trip
             float av0[TN], bv0[TK], av1[TN], bv1[TK];
             auto lds_frags = [&](int s, float (&av)[TN], float (&bv)[TK]) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) av[i] = ap[2 * s * ROWF + 32 * i];
+                for (int i = 0; i < TN; ++i) av[i] = ap[2 * s * NW + 32 * i];
 #pragma unroll
-                for (int j = 0; j < TK; ++j) bv[j] = bp[2 * s * ROWF + 32 * j];
+                for (int j = 0; j < TK; ++j) bv[j] = bp[2 * s * KW + 32 * j];
             };
             auto mma = [&](float (&av)[TN], float (&bv)[TK]) {
 #pragma unroll
@@ -246,9 +250,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
             lds_frags(0, av0, bv0);
 #pragma unroll
             for (int s = 0; s < 16; s += 2) {
-                // waves 4-7 share their SIMDs with waves 0-3: they stage the next chunk in the middle
-                // of their MFMA block, waves 0-3 at its end, so the two never leave a pipe idle together
-                if (s == 8 && more && late) lstore(nbuf);
                 lds_frags(s + 1, av1, bv1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(av0, bv0);
@@ -259,11 +260,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (a.bslab && tid < NW) {
-#pragma unroll 8
-            for (int s = 0; s < 32; ++s) bsum += buf[s * ROWF + tid];
+        if (a.bslab) {
+#pragma unroll
+            for (int s = 0; s < BROWS; ++s) bsum += buf[(brow0 + s) * NW + bcol];
         }
-        if (more && !late) lstore(nbuf);
+        if (RANK1) {
+#pragma unroll
+            for (int s = 0; s < XROWS; ++s) {
+                const float qv = buf[32 * ROWF + xrow0 + s];
+                xsum = fmaf(qv, buf[32 * NW + (xrow0 + s) * KW + xcol], xsum);
+                qsum += qv;
+            }
+        }
         __syncthreads();
     }
     if (active) {
@@ -280,15 +288,41 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
                 }
             }
     }
-    if (a.bslab && tid < NW) a.bslab[(size_t)bid * NW + tid] = bsum;
+    // the last barrier of the loop has passed: the staging buffers are free for the cross-group sums
+    if (a.bslab) smem[tid] = bsum;
+    if (RANK1) {
+        smem[512 + tid] = xsum;
+        if (xcol == 0) smem[1024 + tid / KW] = qsum;
+    }
+    __syncthreads();
+    if (a.bslab && tid < NW) {
+        float t = smem[tid];
+#pragma unroll
+        for (int g = 1; g < BGRP; ++g) t += smem[tid + g * NW];
+        a.bslab[(size_t)bid * NW + tid] = t;
+    }
+    if (RANK1 && tid < KW) {
+        float t = smem[512 + tid];
+#pragma unroll
+        for (int g = 1; g < XGRP; ++g) t += smem[512 + tid + g * KW];
+        a.qslab[(size_t)bid * KW + tid] = t;
+        if (tid == 0) {
+            float u = smem[1024];
+#pragma unroll
+            for (int g = 1; g < XGRP; ++g) u += smem[1024 + g];
+            a.qbslab[bid] = u;
+        }
+    }
 }
 
-// thin products on the VALU: slab[g][b][a] = sum_m P[m][a] * Q[m][b], a < AW (thread), b < NB <= 4.
-// Optional column sums of P (wide bias) and of Q (thin bias).
+// thin products on the VALU: slab[g][b][a] = sum_m P[m][a] * Q[m][b], a < AW (128 or 256), b < NB <= 4,
+// Q stored [Mp][4].  Optional column sums of P (wide bias) and of Q (thin bias).
+// A thread owns 4 adjacent columns of P (16-byte loads, a whole row per 32 or 64 threads) and every
+// RP-th row of the workgroup's row range, 4 rows in flight; the RP row groups are added through LDS.
 struct ThinArgs {
     const float* P;  // [Mp][ldp]
-    const float* Q;  // [Mp][ldq]
-    int ldp, ldq, AW, NB;
+    const float* Q;  // [Mp][4]
+    int ldp, AW, NB;
     int64_t Mp;
     float* slab;     // [G][NB][AW]
     float* pslab;    // [G][AW] or NULL
@@ -296,45 +330,61 @@ struct ThinArgs {
 };
 
 __global__ __launch_bounds__(256) void thin_kernel(ThinArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[8 * 5 * 128];  // [RP][5][AW]: RP*AW = 1024
+    __shared__ float qred[8][4];
     const int tid = threadIdx.x, G = gridDim.x, bid = blockIdx.x;
+    const int C4 = a.AW / 4, RP = 256 / C4;
+    const int rg = tid / C4, c = tid - rg * C4;
     const int64_t r0 = a.Mp * bid / G, r1 = a.Mp * (bid + 1) / G;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f}, ps = 0.f, qs[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4], ps = {0.f, 0.f, 0.f, 0.f}, qs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    int64_t m = r0 + rg;
+    for (; m + (int64_t)(U - 1) * RP < r1; m += (int64_t)U * RP) {
+        f32x4 p[U], q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            p[u] = *reinterpret_cast<const f32x4*>(a.P + (m + (int64_t)u * RP) * a.ldp + 4 * c);
+            q[u] = *reinterpret_cast<const f32x4*>(a.Q + (m + (int64_t)u * RP) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ps += p[u];
+            qs += q[u];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[b] += p[u] * q[u][b];
+        }
+    }
+    for (; m < r1; m += RP) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(a.P + m * a.ldp + 4 * c);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(a.Q + m * 4);
+        ps += p;
+        qs += q;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] += p * q[b];
+    }
+    // red[rg][b][4c..4c+3], b = 4: column sums of P
+#pragma unroll
+    for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(red + (rg * 5 + b) * a.AW + 4 * c) = acc[b];
+    *reinterpret_cast<f32x4*>(red + (rg * 5 + 4) * a.AW + 4 * c) = ps;
+    if (c == 0)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) qred[rg][b] = qs[b];
+    __syncthreads();
     if (tid < a.AW) {
-        constexpr int U = 8;  // rows in flight per thread: the loop is latency-bound otherwise
-        int64_t m = r0;
-        for (; m + U <= r1; m += U) {
-            float p[U], q[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                p[u] = a.P[(m + u) * a.ldp + tid];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) q[u][b] = b < a.NB ? a.Q[(m + u) * a.ldq + b] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                ps += p[u];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    acc[b] = fmaf(p[u], q[u][b], acc[b]);
-                    qs[b] += q[u][b];
-                }
-            }
+        for (int b = 0; b < 5; ++b) {
+            if (b < 4 ? b >= a.NB : a.pslab == nullptr) continue;
+            float t = 0.f;
+            for (int g = 0; g < RP; ++g) t += red[(g * 5 + b) * a.AW + tid];
+            if (b < 4) a.slab[((size_t)bid * a.NB + b) * a.AW + tid] = t;
+            else a.pslab[(size_t)bid * a.AW + tid] = t;
         }
-        for (; m < r1; ++m) {
-            const float p = a.P[m * a.ldp + tid];
-            ps += p;
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (b < a.NB) {
-                    const float qv = a.Q[m * a.ldq + b];
-                    acc[b] = fmaf(p, qv, acc[b]);
-                    qs[b] += qv;
-                }
-        }
-        for (int b = 0; b < a.NB; ++b) a.slab[((size_t)bid * a.NB + b) * a.AW + tid] = acc[b];
-        if (a.pslab) a.pslab[(size_t)bid * a.AW + tid] = ps;
-        if (a.qslab && tid == 0)
-            for (int b = 0; b < 4; ++b) a.qslab[(size_t)bid * 4 + b] = qs[b];
+    }
+    if (a.qslab && tid < 4) {
+        float t = 0.f;
+        for (int g = 0; g < RP; ++g) t += qred[g][tid];
+        a.qslab[(size_t)bid * 4 + tid] = t;
     }
 }
 
@@ -378,31 +428,44 @@ void reduce(Ctx& c, const float* slab, int G, int rows, int cols, int cols_valid
     c.rc = nerf_check_launch("wgrad reduce");
 }
 
-// dW[:, koff : koff+kvalid] (leading dimension ldw) = dY^T X ; db = column sums of dY (if db)
-template <int NW, int KW, int WN, int WK>
-void wgrad(Ctx& c, const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int kvalid, float* db) {
+// dW[:, 0:kvalid] (leading dimension ldw) = dY^T X ; db = column sums of dY (if db).
+// RANK1: additionally qrow[0:kvalid] = sum_m q[m] X[m][:] and *qbias = sum_m q[m].
+template <int NW, int KW, int WN, int WK, bool RANK1 = false>
+void wgrad(Ctx& c, const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int kvalid, float* db,
+           const float* q = nullptr, float* qrow = nullptr, float* qbias = nullptr) {
     if (c.rc) return;
     const int nchunks = (int)(c.Mp / 32);
     const int G = nchunks < lay::WG_MAX ? nchunks : lay::WG_MAX;
     float* bslab = c.slab + (size_t)G * NW * KW;
-    WgradArgs a{dY, X, ldy, ldx, nchunks, c.slab, db ? bslab : nullptr};
-    auto kern = wgrad_kernel<NW, KW, WN, WK>;
+    float* qslab = bslab + (size_t)G * NW;
+    float* qbslab = qslab + (size_t)G * KW;
+    WgradArgs a{dY, X, ldy, ldx, nchunks, c.slab, db ? bslab : nullptr, q, qslab, qbslab};
+    auto kern = wgrad_kernel<NW, KW, WN, WK, RANK1>;
     if ((c.rc = set_lds(kern, wgrad_lds_bytes<NW, KW>()))) return;
     kern<<<G, 512, wgrad_lds_bytes<NW, KW>(), c.st>>>(a);
     if ((c.rc = nerf_check_launch("wgrad"))) return;
     reduce(c, c.slab, G, NW, KW, kvalid, dW, ldw, 1);
     if (db) reduce(c, bslab, G, 1, NW, NW, db, 0, 1);
+    if (RANK1) {
+        reduce(c, qslab, G, 1, KW, kvalid, qrow, 0, 1);
+        reduce(c, qbslab, G, 1, 1, 1, qbias, 0, 1);
+    }
 }
 
-// out[a*sa + b*sb] = sum_m P[m][a] Q[m][b]; optional db_wide[a] = sum_m P[m][a], db_thin[b] = sum_m Q[m][b]
-void thin(Ctx& c, const float* P, int ldp, int AW, const float* Q, int ldq, int NB, float* out, int sa, int sb,
-          float* db_wide, float* db_thin) {
+// out[a*sa + b*sb] = sum_m P[m][a] Q[m][b] (Q stored [Mp][4]); optional db_wide[a] = sum_m P[m][a],
+// db_thin[b] = sum_m Q[m][b]
+void thin(Ctx& c, const float* P, int ldp, int AW, const float* Q, int NB, float* out, int sa, int sb, float* db_wide,
+          float* db_thin) {
     if (c.rc) return;
+    if ((AW != 128 && AW != 256) || NB < 1 || NB > 4) {
+        c.rc = nerf_fail(NERF_E_ARG, "thin wgrad: unsupported shape %d x %d", AW, NB);
+        return;
+    }
     int64_t G = (int64_t)c.Mp / 64;
     if (G > 512) G = 512;
     float* pslab = c.slab + (size_t)G * NB * AW;
     float* qslab = pslab + (size_t)G * AW;
-    ThinArgs a{P, Q, ldp, ldq, AW, NB, (int64_t)c.Mp, c.slab, db_wide ? pslab : nullptr, db_thin ? qslab : nullptr};
+    ThinArgs a{P, Q, ldp, AW, NB, (int64_t)c.Mp, c.slab, db_wide ? pslab : nullptr, db_thin ? qslab : nullptr};
     thin_kernel<<<(unsigned)G, 256, 0, c.st>>>(a);
     if ((c.rc = nerf_check_launch("thin wgrad"))) return;
     reduce(c, c.slab, (int)G, NB, AW, AW, out, sb, sa);
@@ -467,11 +530,12 @@ extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_works
         wgrad<256, 256, 2, 4>(c, dz(5), H, h(4), H, W(5), H + PE, H, B(5));
         wgrad<256, 64, 8, 1>(c, dz(5), H, pe, PE_P, W(5) + H, H + PE, PE, nullptr);
         for (int l = 6; l <= 8; ++l) wgrad<256, 256, 2, 4>(c, dz(l), H, h(l - 1), H, W(l), H, H, B(l));
-        wgrad<256, 256, 2, 4>(c, bw + BW_DZ9 * Mp, H, h(8), H, W(9), H, H, B(9));
-        thin(c, h(8), H, H, bw + BW_DSIG * Mp, 1, 1, W(9) + (size_t)H * H, 1, 0, nullptr, B(9) + H);
+        // block2.8: rows 0..255 from dz9, row 256 (density) is the rank-1 product of dsig with the same h8
+        wgrad<256, 256, 2, 4, true>(c, bw + BW_DZ9 * Mp, H, h(8), H, W(9), H, H, B(9), bw + BW_DSIG * Mp,
+                                    W(9) + (size_t)H * H, B(9) + H);
         wgrad<128, 256, 2, 4>(c, bw + BW_DZ10 * Mp, HH, ws + WS_F * Mp, H, W(10), H + DE, H, B(10));
         wgrad<128, 32, 4, 1>(c, bw + BW_DZ10 * Mp, HH, de, DE_P, W(10) + H, H + DE, DE, nullptr);
-        thin(c, ws + WS_G * Mp, HH, HH, bw + BW_DZ11 * Mp, 4, 3, W(11), 1, HH, nullptr, B(11));
+        thin(c, ws + WS_G * Mp, HH, HH, bw + BW_DZ11 * Mp, 3, W(11), 1, HH, nullptr, B(11));
         return c.rc;
     } else {
         using namespace lay::siren;
@@ -481,13 +545,13 @@ extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_works
         auto h = [&](int l) { return ws + (WS_H + (size_t)l * H) * Mp; };
         auto dz = [&](int l) { return bw + (BW_DZ + (size_t)l * H) * Mp; };
         // layer 0: dW0[n][k] = sum_m dz0[m][n] xn[m][k]
-        thin(c, dz(0), H, H, ws + WS_X * Mp, 4, 3, W(0), 3, 1, B(0), nullptr);
+        thin(c, dz(0), H, H, ws + WS_X * Mp, 3, W(0), 3, 1, B(0), nullptr);
         for (int l = 1; l <= 7; ++l) wgrad<256, 256, 2, 4>(c, dz(l), H, h(l - 1), H, W(l), H, H, B(l));
-        thin(c, h(7), H, H, bw + BW_DSIG * Mp, 1, 1, W(8), 1, 0, nullptr, B(8));
-        wgrad<256, 256, 2, 4>(c, bw + BW_DZF * Mp, H, h(7), H, W(9), H, H, B(9));
+        // feature_remap and the density branch (rank-1 product of dsig) both contract with h7
+        wgrad<256, 256, 2, 4, true>(c, bw + BW_DZF * Mp, H, h(7), H, W(9), H, H, B(9), bw + BW_DSIG * Mp, W(8), B(8));
         wgrad<128, 256, 2, 4>(c, bw + BW_DZR * Mp, HH, ws + WS_F * Mp, H, W(10), H + DE, H, B(10));
         wgrad<128, 32, 4, 1>(c, bw + BW_DZR * Mp, HH, ws + WS_DE * Mp, DE_P, W(10) + H, H + DE, DE, nullptr);
-        thin(c, ws + WS_G * Mp, HH, HH, bw + BW_DZO * Mp, 4, 3, W(11), 1, HH, nullptr, B(11));
+        thin(c, ws + WS_G * Mp, HH, HH, bw + BW_DZO * Mp, 3, W(11), 1, HH, nullptr, B(11));
         return c.rc;
     }
 }

@@ -114,9 +114,10 @@ constexpr size_t BW_DZ = 0, BW_DZF = 8 * H, BW_DZR = BW_DZF + H, BW_DZO = BW_DZR
 constexpr size_t BW_PER_SAMPLE = BW_DSIG + 1;
 }  // namespace siren
 
-// wgrad partial slabs shared by both models: G_MAX workgroups x (256*256 + 256) floats
+// wgrad partial slabs shared by both models: WG_MAX workgroups x (256*256 weight partials + 256 bias
+// partials + 256 + 4 partials of the rank-1 density row and its bias) floats
 constexpr int WG_MAX = 256;
-constexpr size_t SLAB_FLOATS = (size_t)WG_MAX * ((size_t)H * H + H);
+constexpr size_t SLAB_FLOATS = (size_t)WG_MAX * ((size_t)H * H + 2 * H + 4);
 
 inline size_t padded_samples(long long M) { return (size_t)((M + TILE - 1) / TILE) * TILE; }
 
