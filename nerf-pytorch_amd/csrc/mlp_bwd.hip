@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256, 2) void nerf_dgrad_kernel(BwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t m0 = (size_t)blockIdx.x * TILE;
-    stagger_second_resident_group();
     const size_t Mp = a.Mp;
     const float* __restrict__ pk = a.pk;
     const float* ws = a.ws;
@@ -128,7 +127,6 @@ __global__ __launch_bounds__(256, 2) void siren_dgrad_kernel(BwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t m0 = (size_t)blockIdx.x * TILE;
-    stagger_second_resident_group();
     const size_t Mp = a.Mp;
     const float* __restrict__ pk = a.pk;
     const float* ws = a.ws;

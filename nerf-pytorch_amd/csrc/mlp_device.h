@@ -24,17 +24,7 @@ constexpr int ACT_FLOATS = lay::TILE * LDA;
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIN = 2 };
 
-#ifndef NERF_EXP
-#define NERF_EXP 0   // diagnostic timing builds only: 1 no epilogue LDS writes, 2 no layer barriers, 4 one WG per CU
-#endif
-#if (NERF_EXP & 2)
-#define LAYER_SYNC() ((void)0)
-#else
 #define LAYER_SYNC() __syncthreads()
-#endif
-#ifndef STAGGER_SLEEPS
-#define STAGGER_SLEEPS 5   // x 127*64 cycles: about half of one 256x256 layer on a shared pipe
-#endif
 
 __device__ __forceinline__ f32x16 splat16(float v) {
     f32x16 r;
@@ -148,11 +138,7 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                     nerf_sincosf(v, &s, &c);
                     v = s;
                 }
-#if (NERF_EXP & 1)
-                asm volatile("" ::"v"(v));
-#else
                 act[row * LDA + col] = v;
-#endif
                 if constexpr (STORE_COS && ACT == ACT_SIN) gcos[(size_t)row * ldg + col] = c;
             }
         }
@@ -208,23 +194,6 @@ __device__ __forceinline__ void encode_axis(float* dst, int axis, float x) {
         nerf_sincosf(mul_rn((float)(1 << j), x), &s, &c);
         dst[3 + 6 * j + axis] = s;
         dst[3 + 6 * j + 3 + axis] = c;
-    }
-}
-
-// Two workgroups share every CU (and every SIMD's matrix pipe).  Launched together and running
-// the same program on equal tiles they stay in lockstep: both reach their epilogues (no MFMA
-// work) at the same time and the pipe idles.  The second half of the first resident wave of
-// workgroups therefore starts half a layer late; every tile takes the same time, so the
-// offset persists for the whole launch.  Placement is only a speed matter, never correctness.
-__device__ __forceinline__ void stagger_second_resident_group() {
-    if (blockIdx.x < 512u) {
-        // HW_REG_HW_ID (register 4) bits [3:0]: this wave's slot on its SIMD; the two workgroups
-        // that share a CU in the first resident generation sit in slots of different parity
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-        if (slot & 1u) {
-#pragma unroll 1
-            for (int i = 0; i < STAGGER_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
-        }
     }
 }
 

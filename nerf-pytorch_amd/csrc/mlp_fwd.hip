@@ -158,11 +158,7 @@ struct FwdArgs {
 };
 
 constexpr int XIN_FLOATS = lay::TILE * 8;
-#if (NERF_EXP & 4)
-constexpr int FWD_LDS_BYTES = 100 * 1024;
-#else
 constexpr int FWD_LDS_BYTES = (ACT_FLOATS + XIN_FLOATS + lay::TILE) * 4;
-#endif
 
 __device__ __forceinline__ float norm_coord(float p, float nearf, float spanf) {
 #pragma clang fp contract(off)  // each operation rounded on its own, as the reference's tensor ops are
@@ -253,21 +249,6 @@ __device__ __forceinline__ void head_out(const float* act, const float* __restri
     }
 }
 
-#if (NERF_EXP & 8)
-// diagnostic timeline: first 1024 workgroups, wave 0, 100 MHz global counter per phase + HW ids
-__device__ unsigned long long g_stamps[1024][32];
-#define STAMP(i)                                                                             \
-    do {                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        if (blockIdx.x < 1024 && tid == 0) {                                                 \
-            g_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime();                      \
-            g_stamps[blockIdx.x][14 + (i)] = __builtin_amdgcn_s_memtime();                   \
-        }                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-    } while (0)
-#else
-#define STAMP(i) ((void)0)
-#endif
 
 // one 256 -> 256 layer on the tile: bias, MFMA loop, barrier, epilogue, barrier
 template <int ACT, bool TRAIN>
@@ -278,13 +259,9 @@ __device__ __forceinline__ void hidden_layer(float* act, const float* __restrict
     f32x16 acc[2][2];
     init_bias<2>(acc, bias, ncol0, lane);
     mma_layer<2>(act, img, lay::H, kb_count, ncol0, lane, acc);
-    STAMP(20 + (kb_count == 32 ? 0 : 4));
     LAYER_SYNC();
-    STAMP(21 + (kb_count == 32 ? 0 : 4));
     fwd_epilogue<2, ACT, TRAIN>(act, acc, ncol0, lane, gcos, lay::H, TRAIN ? relu_mask : nullptr);
-    STAMP(22 + (kb_count == 32 ? 0 : 4));
     LAYER_SYNC();
-    STAMP(23 + (kb_count == 32 ? 0 : 4));
     // the next layer only reads the tile, so this copy needs no barrier of its own
     if constexpr (TRAIN) store_tile(act, lay::H, gout, lay::H, tid);
 }
@@ -300,7 +277,6 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t m0 = (size_t)blockIdx.x * TILE;
-    stagger_second_resident_group();
     const float* __restrict__ pk = a.pk;
     float* ws = a.ws;
     const size_t Mp = a.Mp;
@@ -310,30 +286,19 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         return TRAIN ? reinterpret_cast<unsigned long long*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid : nullptr;
     };
 
-    STAMP(0);
-#if (NERF_EXP & 8)
-    if (blockIdx.x < 1024 && tid == 0) {
-        g_stamps[blockIdx.x][30] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
-        g_stamps[blockIdx.x][31] = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // XCC_ID
-    }
-#endif
     load_inputs(a, m0, xin, tid);
     __syncthreads();
-    STAMP(1);
     encode_pe(act, xin, tid);
     __syncthreads();
-    STAMP(2);
     if constexpr (TRAIN) store_tile(act, PE_P, wsp(WS_PE, PE_P), PE_P, tid);
 
     const int ncol0 = wave * 64;
     // L0: K 64
     hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L0, PE_P / 8, pk + BIAS, ncol0, tid, wsp(WS_H, H), nullptr, mskp(0));
-    STAMP(3);
     // L1..L4
     for (int l = 1; l <= 4; ++l) {
         hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
                                       tid, wsp(WS_H + (size_t)l * H, H), nullptr, mskp(l));
-        STAMP(3 + l);
     }
     // L5: [h4 | pe] in two passes over the same accumulators
     {
@@ -349,12 +314,10 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         __syncthreads();
         if constexpr (TRAIN) store_tile(act, H, wsp(WS_H + 5 * (size_t)H, H), H, tid);
     }
-    STAMP(8);
     // L6..L8
     for (int l = 6; l <= 8; ++l)
         hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L6 + (size_t)(l - 6) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
                                       tid, wsp(WS_H + (size_t)l * H, H), nullptr, mskp(l));
-    STAMP(9);
     // L9: 256 feature columns on MFMA, density column on the VALU
     {
         f32x16 acc[2][2];
@@ -370,7 +333,6 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         __syncthreads();
         if constexpr (TRAIN) store_tile(act, H, wsp(WS_F, H), H, tid);
     }
-    STAMP(10);
     // L10: [f | de] -> 128, two passes
     {
         const int nc = wave * 32;
@@ -387,10 +349,8 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         __syncthreads();
         if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
     }
-    STAMP(12);
     // L11 + sigmoid, density = relu(raw)
     head_out(act, pk + W11, pk + BIAS11, 1.0f, fmaxf(sraw_s[tid >> 2], 0.0f), m0, a.M, a.colors, a.density, tid);
-    STAMP(13);
 }
 
 template <bool TRAIN>
@@ -404,7 +364,6 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t m0 = (size_t)blockIdx.x * TILE;
-    stagger_second_resident_group();
     const float* __restrict__ pk = a.pk;
     float* ws = a.ws;
     const size_t Mp = a.Mp;
@@ -526,8 +485,3 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
     return nerf_check_launch("nerf_mlp_fwd");
 }
 
-#if (NERF_EXP & 8)
-extern "C" int nerf_debug_stamps(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 1024 * 32);
-}
-#endif

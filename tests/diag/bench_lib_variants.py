@@ -1,5 +1,5 @@
 import os, sys, subprocess, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for lib in sys.argv[1:]:
     env = dict(os.environ, NERF_HIP_LIB=os.path.join(ROOT, "nerf-pytorch_amd", "lib", lib))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sampling", "single", "--steps", "6", "--warmup", "2",

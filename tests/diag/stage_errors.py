@@ -1,6 +1,6 @@
 """Stage-by-stage GPU vs oracle error report (not a pytest; run on the GPU box)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "nerf-pytorch_amd"))
 import numpy as np, torch
 from oracle import nerf_oracle as O
