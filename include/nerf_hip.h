@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 2
+#define NERF_ABI_VERSION 3
 
 #define NERF_OK 0
 #define NERF_E_ARG (-1)      /* bad shape / size / unsupported configuration */
@@ -115,6 +115,20 @@ int nerf_mlp_pack(int model, const float* const* params, float* packed, void* st
 int nerf_mlp_fwd(int model, const float* packed, int64_t M, const float* points, const float* dirs,
                  const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near,
                  double far, float* colors, float* density, float* workspace, void* stream);
+
+/* ---- opt-in bf16 inference mode (NERF_MODEL_NERF only; no counterpart in the reference, which is
+ * fp32 throughout) ------------------------------------------------------------------------------
+ * Same computation as nerf_mlp_fwd without a workspace, with every weight and every layer input
+ * (encodings and activations) rounded to bf16 and fp32 accumulation (v_mfma_f32_32x32x16_bf16);
+ * biases, the sigmoid and the sample positions stay fp32.  Not a parity path: expect about 1e-2
+ * absolute deviation of colors from the fp32 kernels.  `packed` is an image of
+ * nerf_mlp_packed_bf16_bytes(model) BYTES built by nerf_mlp_pack_bf16 (re-run after every
+ * parameter change); it is unrelated to the fp32 image of nerf_mlp_pack. */
+size_t nerf_mlp_packed_bf16_bytes(int model);                  /* 0 for models without a bf16 kernel */
+int nerf_mlp_pack_bf16(int model, const float* const* params, void* packed, void* stream);
+int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const float* points, const float* dirs,
+                      const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near,
+                      double far, float* colors, float* density, void* stream);
 
 /* Backward of nerf_mlp_fwd wrt the 24 parameter tensors.
  * dcolors [M,3], ddensity [M]: upstream gradients; colors: the forward's output.

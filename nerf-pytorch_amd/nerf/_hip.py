@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 MODEL_NERF = 0
 MODEL_SIREN = 1
 NUM_PARAM_TENSORS = 24
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -45,6 +45,9 @@ _SIGS = {
     "nerf_mlp_bwd_workspace_floats": (c_size_t, [c_int, c_int64]),
     "nerf_mlp_pack": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
     "nerf_mlp_fwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P, _P, _P, _P]),
+    "nerf_mlp_packed_bf16_bytes": (c_size_t, [c_int]),
+    "nerf_mlp_pack_bf16": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
+    "nerf_mlp_fwd_bf16": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P, _P, _P]),
     "nerf_merge_samples": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "nerf_mlp_bwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "nerf_mlp_bwd_data": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P]),
@@ -242,6 +245,34 @@ def mlp_fwd(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None,
            "nerf_mlp_fwd")
     timers.stop(ev)
     return colors, density, ws
+
+
+def mlp_pack_bf16(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 weight image (a uint8 tensor) for mlp_fwd_bf16."""
+    if len(params) != NUM_PARAM_TENSORS:
+        raise ValueError(f"expected {NUM_PARAM_TENSORS} parameter tensors, got {len(params)}")
+    nbytes = lib.nerf_mlp_packed_bf16_bytes(model)
+    if nbytes == 0:
+        raise NotImplementedError("the bf16 inference mode covers the NeRF model only")
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=params[0].device)
+    ptrs = (c_void_p * NUM_PARAM_TENSORS)(*[_dev(p, f"params[{i}]") for i, p in enumerate(params)])
+    _check(lib.nerf_mlp_pack_bf16(model, ptrs, _dev(out, "packed", torch.uint8), _stream()), "nerf_mlp_pack_bf16")
+    return out
+
+
+def mlp_fwd_bf16(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None, rays_o=None, rays_d=None, t=None,
+                 S: int = 0, near: float = 0.0, far: float = 1.0):
+    dev = packed.device
+    colors = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    density = torch.empty((M,), dtype=torch.float32, device=dev)
+    ev = timers.start("mlp_fwd_infer_bf16", M)
+    _check(lib.nerf_mlp_fwd_bf16(model, _dev(packed, "packed", torch.uint8), M, _opt(points, "points"),
+                                 _opt(dirs, "dirs"), _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S,
+                                 int(t is not None and t.dim() == 2), float(near), float(far),
+                                 _dev(colors, "colors"), _dev(density, "density"), _stream()), "nerf_mlp_fwd_bf16")
+    timers.stop(ev)
+    return colors, density, None
 
 
 def mlp_bwd(model: int, packed: torch.Tensor, M: int, dcolors, ddensity, colors, ws, grads: Optional[torch.Tensor] = None):

@@ -35,6 +35,23 @@ class _FusedMLP(nn.Module):
 
     def _init_fused(self) -> None:
         self._packed = PackedWeights(self.model_id)
+        self._packed_bf16 = None
+        self.inference_precision = "fp32"
+
+    def set_inference_precision(self, precision: str) -> "_FusedMLP":
+        """'fp32' (default, the parity path) or 'bf16': an opt-in mode for renders without gradients
+        (torch.no_grad() / parameters that do not require grad) in which weights, encodings and
+        activations are rounded to bf16 and accumulated in fp32.  Training always runs fp32."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision == "bf16":
+            self._check_supported()
+            if _hip.lib.nerf_mlp_packed_bf16_bytes(self.model_id) == 0:
+                raise NotImplementedError("the bf16 inference mode covers the NeRF model only")
+            if self._packed_bf16 is None:
+                self._packed_bf16 = PackedWeights(self.model_id, _hip.mlp_pack_bf16)
+        self.inference_precision = precision
+        return self
 
     def ordered_parameters(self) -> List[torch.Tensor]:
         """The 24 tensors in state_dict order (the order the C ABI expects)."""
@@ -43,12 +60,18 @@ class _FusedMLP(nn.Module):
             raise RuntimeError(f"expected {_hip.NUM_PARAM_TENSORS} parameter tensors, found {len(ps)}")
         return ps
 
-    def packed_weights(self) -> torch.Tensor:
+    def packed_weights(self, train: bool = True) -> torch.Tensor:
+        """Weight image for the kernels: the fp32 image, or the bf16 one for a gradient-free pass of
+        a module switched to bf16 inference."""
+        if not train and self.inference_precision == "bf16":
+            return self._packed_bf16.get(self.ordered_parameters())
         return self._packed.get(self.ordered_parameters())
 
     def invalidate_packed(self) -> None:
         """Call after modifying parameter memory behind autograd's back (fused optimizer)."""
         self._packed.invalidate()
+        if self._packed_bf16 is not None:
+            self._packed_bf16.invalidate()
 
     def _check_supported(self) -> None:
         raise NotImplementedError
@@ -64,8 +87,8 @@ class _FusedMLP(nn.Module):
         if points.dim() != 2 or points.shape[1] != 3 or rays_d.shape != points.shape:
             raise ValueError("points and rays_d must both be [M,3]")
         params = self.ordered_parameters()
-        return MLPFunction.apply(self.model_id, self.packed_weights(), _f32c(points), _f32c(rays_d),
-                                 wants_grad(params), *params)
+        train = wants_grad(params)
+        return MLPFunction.apply(self.model_id, self.packed_weights(train), _f32c(points), _f32c(rays_d), train, *params)
 
 
 class NeRF(_FusedMLP):

@@ -20,8 +20,9 @@ class PackedWeights:
     """Caches the fragment-ordered weight image of one module and re-packs it whenever
     a parameter was replaced or modified in place (optimizer step, load_state_dict)."""
 
-    def __init__(self, model_id: int):
+    def __init__(self, model_id: int, pack=_hip.mlp_pack):
         self.model_id = model_id
+        self._pack = pack      # _hip.mlp_pack (fp32 image) or _hip.mlp_pack_bf16
         self._key = None
         self._img = None
 
@@ -33,7 +34,7 @@ class PackedWeights:
         if key != self._key or self._img is None or self._img.device != params[0].device:
             datas = [_f32c(p.detach()) for p in params]
             reuse = self._img is not None and self._img.device == params[0].device
-            self._img = _hip.mlp_pack(self.model_id, datas, self._img if reuse else None)
+            self._img = self._pack(self.model_id, datas, self._img if reuse else None)
             self._key = key
         return self._img
 
@@ -43,6 +44,15 @@ def wants_grad(params: Sequence[torch.Tensor]) -> bool:
     the caller: inside autograd.Function.forward grad mode is always off and needs_input_grad
     ignores torch.no_grad()."""
     return torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
+
+def _mlp_fwd(model_id, packed, M, train, **inputs):
+    """The fp32 kernel, or the opt-in bf16 inference kernel when handed a bf16 image (uint8)."""
+    if packed.dtype == torch.uint8:
+        if train:
+            raise RuntimeError("the bf16 mode is inference-only; training runs the fp32 kernels")
+        return _hip.mlp_fwd_bf16(model_id, packed, M, **inputs)
+    return _hip.mlp_fwd(model_id, packed, M, train=train, **inputs)
 
 
 def _split_grads(flat: torch.Tensor, params: Sequence[torch.Tensor]):
@@ -61,7 +71,7 @@ class MLPFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model_id, packed, points, dirs, train, *params):
         M = points.shape[0]
-        colors, density, ws = _hip.mlp_fwd(model_id, packed, M, points=points, dirs=dirs, train=train)
+        colors, density, ws = _mlp_fwd(model_id, packed, M, train, points=points, dirs=dirs)
         ctx.model_id, ctx.M, ctx.train = model_id, M, train
         ctx.nparams = len(params)
         if train:
@@ -97,8 +107,8 @@ class RenderFunction(torch.autograd.Function):
     def forward(ctx, model_id, packed, rays_o, rays_d, t, deltas, near, far, white, want_extras, train, *params):
         R, S = rays_o.shape[0], t.shape[-1]   # t is [S] (shared) or [R,S] (per ray)
         M = R * S
-        colors, density, ws = _hip.mlp_fwd(model_id, packed, M, rays_o=rays_o, rays_d=rays_d, t=t, S=S, near=near,
-                                           far=far, train=train)
+        colors, density, ws = _mlp_fwd(model_id, packed, M, train, rays_o=rays_o, rays_d=rays_d, t=t, S=S, near=near,
+                                       far=far)
         colors = colors.view(R, S, 3)
         density = density.view(R, S)
         rgb, weights, depth, acc = _hip.composite_fwd(colors, density, deltas, white, t=t, want_weights=want_extras,

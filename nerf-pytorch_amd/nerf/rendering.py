@@ -104,8 +104,8 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
     if fused:
         model._check_supported()
         params = model.ordered_parameters()
-        packed = model.packed_weights()
         train = wants_grad(params)
+        packed = model.packed_weights(train)
     outs, extras = [], []
     for ci, i in enumerate(range(0, rays_o.shape[0], chunk_size)):
         o_chunk = rays_o[i:i + chunk_size]
@@ -160,8 +160,8 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
             raise TypeError("render_nerf_hierarchical needs this package's NeRF/Siren modules")
         m._check_supported()
     pc, pf = coarse.ordered_parameters(), fine.ordered_parameters()
-    wc, wf = coarse.packed_weights(), fine.packed_weights()
     tc_train, tf_train = wants_grad(pc), wants_grad(pf)
+    wc, wf = coarse.packed_weights(tc_train), fine.packed_weights(tf_train)
     out_c, out_f, extras = [], [], []
     for ci, i in enumerate(range(0, rays_o.shape[0], chunk_size)):
         o, d = rays_o[i:i + chunk_size], rays_d[i:i + chunk_size]

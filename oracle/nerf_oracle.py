@@ -222,6 +222,34 @@ def nerf_forward(p: Params, points: Tensor, dirs: Tensor, pos_L: int = 10, dir_L
     return colors, density
 
 
+def bf16_round(x: Tensor) -> Tensor:
+    """fp32 -> bf16 (round to nearest even) -> fp32."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def nerf_forward_bf16(p: Params, points: Tensor, dirs: Tensor):
+    """The opt-in bf16 inference mode (no counterpart in the reference, which is fp32 throughout):
+    nerf_forward with every weight and every layer input (encodings, activations) rounded to bf16,
+    products accumulated in higher precision (float64 here), biases / sigmoid / inputs in fp32."""
+    def lin(x, name):
+        w = bf16_round(p[name + ".weight"]).double()
+        return (bf16_round(x).double() @ w.t() + p[name + ".bias"].double()).float()
+
+    pe = positional_encoding(points, 10)
+    de = positional_encoding(dirs, 4)
+    h = pe
+    for i in range(5):
+        h = torch.relu(lin(h, f"block1.{2*i}"))
+    h = torch.cat([h, pe], dim=1)
+    for i in range(4):
+        h = torch.relu(lin(h, f"block2.{2*i}"))
+    f = lin(h, "block2.8")
+    density = torch.relu(f[:, -1])
+    g = torch.relu(lin(torch.cat([f[:, :-1], de], dim=1), "rgb_head.0"))
+    colors = torch.sigmoid(lin(g, "rgb_head.2"))
+    return colors, density
+
+
 def siren_forward(p: Params, points: Tensor, dirs: Tensor, num_layers: int = 8, dir_L: int = 4,
                   w0: float = 30.0, hidden_w0: float = 1.0, sigma_mul: float = 10.0,
                   rgb_mul: float = 1.0, return_acts: bool = False):
