@@ -35,6 +35,7 @@ FLOPS = {
     "siren": {"fwd": 2 * 561920, "dgrad": 2 * (561920 - 3 * 256 - 27 * 128), "wgrad": 2 * 561920},
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (without sparsity)
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per MLP evaluation from the committed rocprofv3 --pmc passes (profiles/r1_pmc_fetch.csv,
 # r1_pmc_write.csv: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch / 1,048,576 samples; FETCH_SIZE
@@ -134,6 +135,8 @@ def main():
                          "'64+128 samples/ray'); single: the reference's own single pass of --samples (config_lego.txt:15)")
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=128)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: the opt-in inference mode (--mode infer, nerf only); never the default metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     args = ap.parse_args()
@@ -160,6 +163,11 @@ def main():
     Model = NeRF if args.model == "nerf" else Siren
     models = [Model().to(dev) for _ in range(2 if hier else 1)]   # [coarse, fine] or [single]
     model = models[0]
+    if args.precision == "bf16":
+        if args.mode != "infer":
+            raise SystemExit("--precision bf16 is an inference-only mode: add --mode infer")
+        for m in models:
+            m.set_inference_precision("bf16")
     flats = [parallel.FlatParameters(m) for m in models]
     for f in flats:
         f.broadcast_parameters(0)
@@ -236,7 +244,8 @@ def main():
                      ("mlp_bwd_data", fl["dgrad"], "fused data-gradient chain"),
                      ("mlp_bwd_weights", fl["wgrad"], "per-layer weight-gradient GEMMs + reductions (launch group)")]
         else:
-            specs = [("mlp_fwd_infer", fl["fwd"], "fused sample+encode+MLP forward (inference)")]
+            specs = [("mlp_fwd_infer", fl["fwd"], "fused sample+encode+MLP forward (inference)"),
+                     ("mlp_fwd_infer_bf16", fl["fwd"], "bf16 opt-in: register-chain encode+MLP forward (inference)")]
         for name, flop_per_sample, desc in specs:
             if name in tm:
                 n, ms_total, samples = tm[name]
@@ -254,8 +263,9 @@ def main():
             per_sample = dict((n_, f_) for n_, f_, _ in specs)[dom]
             samples_per_launch = kernels[dom]["flop_per_launch"] / per_sample
             tb = TRAFFIC_BYTES_PER_SAMPLE.get((args.model, dom))
-            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": tb * samples_per_launch if tb else None,
+            peak = PEAK_BF16_MFMA_TFLOPS if dom.endswith("bf16") else PEAK_F32_MFMA_TFLOPS
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                    "frac": ach / peak, "traffic": tb * samples_per_launch if tb else None,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc passes of this build, profiles/)",
                     "ms_per_launch": kernels[dom]["ms_per_launch"], "flop_per_launch": kernels[dom]["flop_per_launch"],
                     "flop_per_sample": per_sample, "samples_per_launch": samples_per_launch}
@@ -267,17 +277,18 @@ def main():
                       else f"inference rays/sec ({S} MLP evaluations/ray)",
             "value": world * B * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"lego-shaped synthetic {args.res}x{args.res} scene, {B} rays/GPU/step, "
                                    + (f"{args.coarse} coarse + ({args.coarse}+{args.fine}) fine = {S} MLP evaluations/ray, "
                                       f"coarse+fine {args.model} MLPs" if hier else
                                       f"{S} samples/ray single pass, one {args.model} MLP")
-                                   + f" (fp32 MFMA), {args.mode}", "model": args.model, "sampling": args.sampling,
+                                   + (" (bf16 MFMA, fp32 accumulate)" if args.precision == "bf16" else " (fp32 MFMA)") + f", {args.mode}", "model": args.model, "sampling": args.sampling,
                        "rays_per_gpu": B, "global_batch": B * world, "mlp_evals_per_ray": S,
                        "parallelism": f"dp{world} ray-sharded, flat-bucket RCCL all-reduce" if world > 1 else "single GPU"},
             "roofline": roof,
             "kernels": kernels,
-            "step_mfma_frac": (total_flop / (ms_step * 1e-3) / 1e12) / PEAK_F32_MFMA_TFLOPS,
+            "step_mfma_frac": (total_flop / (ms_step * 1e-3) / 1e12)
+                              / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
             "final_value": final,
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":
