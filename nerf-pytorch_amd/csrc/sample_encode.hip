@@ -58,26 +58,44 @@ extern "C" int nerf_stratified_t(double near, double far, int S, const float* u,
 }
 
 // ---------------------------------------------------------------------------------------
-// positions: one thread per sample, 12 B each, a wave writes 768 contiguous bytes
+// positions: one thread per 4 consecutive output floats (one 16-byte store, a wave writes 1 KiB
+// contiguous); output float f belongs to sample f/3, coordinate f%3
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float normalize_coord(float p, float nearf, float spanf) {
     // 2*(p-near)/(far-near)-1: sub, mul by 2, true division, sub 1 (rendering.py:82)
     return sub_rn(div_rn(mul_rn(2.0f, sub_rn(p, nearf)), spanf), 1.0f);
 }
 
-__global__ void sample_positions_kernel(const float* __restrict__ o, const float* __restrict__ d,
-                                        const float* __restrict__ t, int64_t R, int S, int normalize, float nearf,
-                                        float spanf, float* __restrict__ pos) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= R * S) return;
-    const int64_t r = m / S;
-    const int s = (int)(m - r * S);
-    const float ts = t[s];
+__global__ __launch_bounds__(256) void sample_positions_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                                              const float* __restrict__ t, int64_t R, int S,
+                                                              int normalize, float nearf, float spanf,
+                                                              float* __restrict__ pos) {
+    // 64-bit index arithmetic only on workgroup-uniform values; per thread 32-bit offsets from them
+    const int64_t total = R * S * 3;
+    const int64_t fb = (int64_t)blockIdx.x * 1024;        // first output float of this workgroup
+    const int64_t mb = fb / 3;                            // its sample ...
+    const int cb = (int)(fb - mb * 3);                    // ... and coordinate
+    const int64_t rb = mb / S;                            // ray and sample-in-ray of that sample
+    const unsigned sb = (unsigned)(mb - rb * S);
+    const int64_t f0 = fb + threadIdx.x * 4;
+    if (f0 >= total) return;
+    float v[4];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float p = add_rn(o[r * 3 + c], mul_rn(ts, d[r * 3 + c]));
+    for (int i = 0; i < 4; ++i) {
+        const unsigned fl = threadIdx.x * 4 + i + cb;     // floats past (mb, coordinate 0)
+        const unsigned ml = fl / 3, c = fl - ml * 3;
+        const unsigned sl = sb + ml, rl = sl / (unsigned)S;
+        int64_t r = rb + rl;
+        const unsigned sidx = sl - rl * (unsigned)S;
+        if (r >= R) r = R - 1;                            // lanes past the end: clamped, not stored
+        float p = add_rn(o[r * 3 + c], mul_rn(t[sidx], d[r * 3 + c]));
         if (normalize) p = normalize_coord(p, nearf, spanf);
-        pos[m * 3 + c] = p;
+        v[i] = p;
+    }
+    if (f0 + 4 <= total) {
+        *reinterpret_cast<f32x4*>(pos + f0) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+        for (int i = 0; f0 + i < total; ++i) pos[f0 + i] = v[i];
     }
 }
 
@@ -89,36 +107,47 @@ extern "C" int nerf_sample_positions(const float* rays_o, const float* rays_d, c
     NERF_REQUIRE_PTR(rays_d);
     NERF_REQUIRE_PTR(t);
     NERF_REQUIRE_PTR(pos);
-    const int64_t M = R * S;
-    NERF_REQUIRE(ceil_div64(M, 256) < (1ll << 31), "nerf_sample_positions: too many samples");
-    sample_positions_kernel<<<(unsigned)ceil_div64(M, 256), 256, 0, (hipStream_t)stream>>>(
+    const int64_t quads = ceil_div64(R * S * 3, 4);
+    NERF_REQUIRE(ceil_div64(quads, 256) < (1ll << 31), "nerf_sample_positions: too many samples");
+    sample_positions_kernel<<<(unsigned)ceil_div64(quads, 256), 256, 0, (hipStream_t)stream>>>(
         rays_o, rays_d, t, R, S, normalize, (float)near, (float)(far - near), pos);
     return nerf_check_launch("nerf_sample_positions");
 }
 
 // ---------------------------------------------------------------------------------------
-// positional encoding: one thread per (sample, frequency slot, coordinate); slot 0 copies x,
-// slot j>=1 writes sin and cos of 2^(j-1) x.  Full-range sinf/cosf (arguments reach ~1e3 rad).
+// positional encoding: a workgroup encodes 64 points into LDS (one thread per point, frequency
+// slot and coordinate; slot 0 copies x, slot j>=1 writes sin and cos of 2^(j-1) x with the
+// full-range sincos: arguments reach ~1e3 rad), then writes its 64 rows, which are contiguous in the
+// output, with 16-byte stores.
 // ---------------------------------------------------------------------------------------
-__global__ void posenc_kernel(const float* __restrict__ x, int64_t M, int D, int L, float* __restrict__ out) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per = D * (L + 1);
-    if (idx >= M * per) return;
-    const int64_t m = idx / per;
-    const int rem = (int)(idx - m * per);
-    const int j = rem / D, c = rem - j * D;
-    const int width = D * (1 + 2 * L);
-    const float v = x[m * D + c];
-    float* row = out + m * width;
-    if (j == 0) {
-        row[c] = v;
-    } else {
-        const float a = mul_rn((float)(1u << (j - 1)), v);
-        float sn, cs;
-        nerf_sincosf(a, &sn, &cs);
-        row[D + 2 * D * (j - 1) + c] = sn;
-        row[D + 2 * D * (j - 1) + D + c] = cs;
+constexpr int PE_POINTS = 64;
+
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x, int64_t M, int D, int L,
+                                                    float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];  // [PE_POINTS][width]
+    const int per = D * (L + 1), width = D * (1 + 2 * L);
+    const int64_t m0 = (int64_t)blockIdx.x * PE_POINTS;
+    const int npts = (int)(M - m0 < PE_POINTS ? M - m0 : PE_POINTS);
+    for (int i = threadIdx.x; i < npts * per; i += 256) {
+        const int ml = i / per, rem = i - ml * per;
+        const int j = rem / D, c = rem - j * D;
+        const float v = x[(m0 + ml) * D + c];
+        float* row = rows + ml * width;
+        if (j == 0) {
+            row[c] = v;
+        } else {
+            float sn, cs;
+            nerf_sincosf(mul_rn((float)(1u << (j - 1)), v), &sn, &cs);
+            row[D + 2 * D * (j - 1) + c] = sn;
+            row[D + 2 * D * (j - 1) + D + c] = cs;
+        }
     }
+    __syncthreads();
+    const int nfl = npts * width;             // m0 * width is a multiple of 4: the block's base is 16-byte aligned
+    float* dst = out + m0 * width;
+    for (int i = threadIdx.x * 4; i + 4 <= nfl; i += 1024)
+        *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(rows + i);
+    for (int i = (nfl & ~3) + threadIdx.x; i < nfl; i += 256) dst[i] = rows[i];
 }
 
 extern "C" int nerf_posenc_fwd(const float* x, int64_t M, int D, int L, float* out, void* stream) {
@@ -127,9 +156,10 @@ extern "C" int nerf_posenc_fwd(const float* x, int64_t M, int D, int L, float* o
     if (M == 0) return NERF_OK;
     NERF_REQUIRE_PTR(x);
     NERF_REQUIRE_PTR(out);
-    const int64_t n = M * D * (L + 1);
-    NERF_REQUIRE(ceil_div64(n, 256) < (1ll << 31), "nerf_posenc_fwd: too many elements");
-    posenc_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>(x, M, D, L, out);
+    const int64_t blocks = ceil_div64(M, PE_POINTS);
+    NERF_REQUIRE(blocks < (1ll << 31), "nerf_posenc_fwd: too many elements");
+    const int lds = PE_POINTS * D * (1 + 2 * L) * 4;   // at most 64 * 132 * 4 = 33,792 bytes
+    posenc_kernel<<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(x, M, D, L, out);
     return nerf_check_launch("nerf_posenc_fwd");
 }
 
