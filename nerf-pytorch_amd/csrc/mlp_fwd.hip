@@ -250,20 +250,28 @@ __device__ __forceinline__ void head_out(const float* act, const float* __restri
 }
 
 
-// one 256 -> 256 layer on the tile: bias, MFMA loop, barrier, epilogue, barrier
+// one 256 -> 256 layer on the tile: bias, MFMA loop, barrier, epilogue, barrier.
+// Training: the INPUT tile of the layer (the previous layer's output, `in_cols` columns) is copied to
+// the workspace right after the MFMA loop that consumed it, while it is still intact in LDS.  The
+// copy's global stores then have the whole epilogue to complete before the next wait on a weight
+// load: vmcnt retires in order, so a store issued just ahead of a load would make that load's
+// wait cover the store's acknowledgement as well.
 template <int ACT, bool TRAIN>
 __device__ __forceinline__ void hidden_layer(float* act, const float* __restrict__ img, int kb_count,
-                                             const float* __restrict__ bias, int ncol0, int tid, float* gout,
-                                             float* gcos, unsigned long long* relu_mask = nullptr) {
+                                             const float* __restrict__ bias, int ncol0, int tid, float* gin, int in_cols,
+                                             float* gcos, unsigned long long* gmask_in = nullptr,
+                                             unsigned long long* mask = nullptr) {
     const int lane = tid & 63;
     f32x16 acc[2][2];
     init_bias<2>(acc, bias, ncol0, lane);
     mma_layer<2>(act, img, lay::H, kb_count, ncol0, lane, acc);
+    if constexpr (TRAIN) {
+        store_tile(act, in_cols, gin, in_cols, tid);
+        if (gmask_in) *gmask_in = *mask;   // ReLU mask word of the input tile's layer, kept in registers until now
+    }
     LAYER_SYNC();
-    fwd_epilogue<2, ACT, TRAIN>(act, acc, ncol0, lane, gcos, lay::H, TRAIN ? relu_mask : nullptr);
+    fwd_epilogue<2, ACT, TRAIN>(act, acc, ncol0, lane, gcos, lay::H, TRAIN ? mask : nullptr);
     LAYER_SYNC();
-    // the next layer only reads the tile, so this copy needs no barrier of its own
-    if constexpr (TRAIN) store_tile(act, lay::H, gout, lay::H, tid);
 }
 
 template <bool TRAIN>
@@ -290,40 +298,48 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
     __syncthreads();
     encode_pe(act, xin, tid);
     __syncthreads();
-    if constexpr (TRAIN) store_tile(act, PE_P, wsp(WS_PE, PE_P), PE_P, tid);
 
     const int ncol0 = wave * 64;
-    // L0: K 64
-    hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L0, PE_P / 8, pk + BIAS, ncol0, tid, wsp(WS_H, H), nullptr, mskp(0));
-    // L1..L4
+    // L0: K 64 (input tile = the position encoding)
+    unsigned long long mask = 0ull;   // ReLU bits of the layer just finished; stored after the next MFMA loop
+    hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L0, PE_P / 8, pk + BIAS, ncol0, tid, wsp(WS_PE, PE_P), PE_P, nullptr, nullptr,
+                                  &mask);
+    // L1..L4 (input tile = h(l-1))
     for (int l = 1; l <= 4; ++l) {
         hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
-                                      tid, wsp(WS_H + (size_t)l * H, H), nullptr, mskp(l));
+                                      tid, wsp(WS_H + (size_t)(l - 1) * H, H), H, nullptr, mskp(l - 1), &mask);
     }
     // L5: [h4 | pe] in two passes over the same accumulators
     {
         f32x16 acc[2][2];
         init_bias<2>(acc, pk + BIAS + 5 * H, ncol0, lane);
         mma_layer<2>(act, pk + F_L5A, H, H / 8, ncol0, lane, acc);
+        if constexpr (TRAIN) {
+            store_tile(act, H, wsp(WS_H + 4 * (size_t)H, H), H, tid);
+            *mskp(4) = mask;
+        }
         __syncthreads();
         encode_pe(act, xin, tid);
         __syncthreads();
         mma_layer<2>(act, pk + F_L5B, H, PE_P / 8, ncol0, lane, acc);
         __syncthreads();
-        fwd_epilogue<2, ACT_RELU, false>(act, acc, ncol0, lane, nullptr, H, mskp(5));
+        fwd_epilogue<2, ACT_RELU, false>(act, acc, ncol0, lane, nullptr, H, TRAIN ? &mask : nullptr);
         __syncthreads();
-        if constexpr (TRAIN) store_tile(act, H, wsp(WS_H + 5 * (size_t)H, H), H, tid);
     }
     // L6..L8
     for (int l = 6; l <= 8; ++l)
         hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L6 + (size_t)(l - 6) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
-                                      tid, wsp(WS_H + (size_t)l * H, H), nullptr, mskp(l));
+                                      tid, wsp(WS_H + (size_t)(l - 1) * H, H), H, nullptr, mskp(l - 1), &mask);
     // L9: 256 feature columns on MFMA, density column on the VALU
     {
         f32x16 acc[2][2];
         init_bias<2>(acc, pk + BIAS + 9 * H, ncol0, lane);
         mma_layer<2>(act, pk + F_L9, H, H / 8, ncol0, lane, acc);
         const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
+        if constexpr (TRAIN) {
+            store_tile(act, H, wsp(WS_H + 8 * (size_t)H, H), H, tid);
+            *mskp(8) = mask;
+        }
         if ((tid & 3) == 0) {
             sraw_s[tid >> 2] = s;
             if constexpr (TRAIN) ws[WS_SRAW * Mp + m0 + (tid >> 2)] = s;
@@ -331,7 +347,6 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         __syncthreads();
         fwd_epilogue<2, ACT_NONE, false>(act, acc, ncol0, lane, nullptr, H);
         __syncthreads();
-        if constexpr (TRAIN) store_tile(act, H, wsp(WS_F, H), H, tid);
     }
     // L10: [f | de] -> 128, two passes
     {
@@ -339,18 +354,19 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         f32x16 acc[2][1];
         init_bias<1>(acc, pk + BIAS10, nc, lane);
         mma_layer<1>(act, pk + F_L10A, HH, H / 8, nc, lane, acc);
+        if constexpr (TRAIN) store_tile(act, H, wsp(WS_F, H), H, tid);
         __syncthreads();
         encode_de(act, xin, tid);
         __syncthreads();
-        if constexpr (TRAIN) store_tile(act, DE_P, wsp(WS_DE, DE_P), DE_P, tid);
         mma_layer<1>(act, pk + F_L10B, HH, DE_P / 8, nc, lane, acc);
+        if constexpr (TRAIN) store_tile(act, DE_P, wsp(WS_DE, DE_P), DE_P, tid);
         __syncthreads();
         fwd_epilogue<1, ACT_RELU, false>(act, acc, nc, lane, nullptr, HH);
         __syncthreads();
-        if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
     }
     // L11 + sigmoid, density = relu(raw)
     head_out(act, pk + W11, pk + BIAS11, 1.0f, fmaxf(sraw_s[tid >> 2], 0.0f), m0, a.M, a.colors, a.density, tid);
+    if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
 }
 
 template <bool TRAIN>
@@ -380,30 +396,27 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
     // layer 0 (3 -> 256, sin(30 z)) on the VALU: thread = output column
     {
         const float w0 = pk[W0 + tid * 3], w1 = pk[W0 + tid * 3 + 1], w2 = pk[W0 + tid * 3 + 2], b = pk[BIAS + tid];
-        float* gh = wsp(WS_H, H);
         float* gc = wsp(WS_C, H);
         for (int s = 0; s < TILE; ++s) {
             const float z = fmaf(xin[s * 8 + 2], w2, fmaf(xin[s * 8 + 1], w1, fmaf(xin[s * 8], w0, b)));
             float sn, cs;
             nerf_sincosf(mul_rn(30.0f, z), &sn, &cs);
             act[s * LDA + tid] = sn;
-            if constexpr (TRAIN) {
-                gh[(size_t)s * H + tid] = sn;
-                gc[(size_t)s * H + tid] = 30.0f * cs;
-            }
+            if constexpr (TRAIN) gc[(size_t)s * H + tid] = 30.0f * cs;
         }
     }
     __syncthreads();
     const int ncol0 = wave * 64;
     for (int l = 1; l <= 7; ++l)
         hidden_layer<ACT_SIN, TRAIN>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), H / 8, pk + BIAS + l * H, ncol0, tid,
-                                     wsp(WS_H + (size_t)l * H, H), wsp(WS_C + (size_t)l * H, H));
+                                     wsp(WS_H + (size_t)(l - 1) * H, H), H, wsp(WS_C + (size_t)l * H, H));
     // feature_remap on MFMA, density branch on the VALU (both read h7)
     {
         f32x16 acc[2][2];
         init_bias<2>(acc, pk + BIAS + 8 * H, ncol0, lane);
         mma_layer<2>(act, pk + F_FEAT, H, H / 8, ncol0, lane, acc);
         const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
+        if constexpr (TRAIN) store_tile(act, H, wsp(WS_H + 7 * (size_t)H, H), H, tid);
         if ((tid & 3) == 0) {
             sraw_s[tid >> 2] = s;
             if constexpr (TRAIN) ws[WS_SRAW * Mp + m0 + (tid >> 2)] = s;
@@ -411,25 +424,25 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
         __syncthreads();
         fwd_epilogue<2, ACT_NONE, false>(act, acc, ncol0, lane, nullptr, H);
         __syncthreads();
-        if constexpr (TRAIN) store_tile(act, H, wsp(WS_F, H), H, tid);
     }
     {
         const int nc = wave * 32;
         f32x16 acc[2][1];
         init_bias<1>(acc, pk + BIAS_RGB, nc, lane);
         mma_layer<1>(act, pk + F_RGBA, HH, H / 8, nc, lane, acc);
+        if constexpr (TRAIN) store_tile(act, H, wsp(WS_F, H), H, tid);
         __syncthreads();
         encode_de(act, xin, tid);
         __syncthreads();
-        if constexpr (TRAIN) store_tile(act, DE_P, wsp(WS_DE, DE_P), DE_P, tid);
         mma_layer<1>(act, pk + F_RGBB, HH, DE_P / 8, nc, lane, acc);
+        if constexpr (TRAIN) store_tile(act, DE_P, wsp(WS_DE, DE_P), DE_P, tid);
         __syncthreads();
         fwd_epilogue<1, ACT_SIN, TRAIN>(act, acc, nc, lane, wsp(WS_CG, HH), HH);
         __syncthreads();
-        if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
     }
     head_out(act, pk + WOUT, pk + BIAS_OUT, 1.0f, fmaxf(sraw_s[tid >> 2], 0.0f) * 10.0f, m0, a.M, a.colors, a.density,
              tid);
+    if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
 }
 
 template <typename K>
