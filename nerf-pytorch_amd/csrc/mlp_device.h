@@ -148,14 +148,15 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
 }
 
 // Backward epilogue: dX = acc (+ rank-1 term) times the activation derivative, written to
-// LDS (next layer's dY) and to the backward workspace (for the weight gradient).
+// LDS (next layer's dY); the tile is copied to the backward workspace (for the weight gradient)
+// later, row-wise, after the next MFMA loop has consumed it.
 //   MASK 1: derivative = (hsrc > 0)         (ReLU; hsrc = the stored post-activation input)
 //   MASK 2: derivative = hsrc               (sine; hsrc = stored w0*cos(w0 z))
 //   MASK 3: derivative = bit of `bits`      (ReLU; the forward's per-lane mask word)
 //   MASK 0: none
 template <int NT, int MASK, bool RANK1>
 __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], int ncol0, int lane,
-                                             const float* __restrict__ hsrc, float* __restrict__ gout, int ldg,
+                                             const float* __restrict__ hsrc, int ldg,
                                              const float* dsig_lds, const float* __restrict__ sigw,
                                              unsigned long long bits = 0ull) {
     const unsigned blo = (unsigned)bits, bhi = (unsigned)(bits >> 32);
@@ -178,7 +179,6 @@ __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                     v = (((bit < 32 ? blo : bhi) >> (bit & 31)) & 1u) ? v : 0.0f;
                 }
                 act[row * LDA + col] = v;
-                gout[(size_t)row * ldg + col] = v;
             }
         }
 }
