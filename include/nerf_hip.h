@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 3
+#define NERF_ABI_VERSION 4
 
 #define NERF_OK 0
 #define NERF_E_ARG (-1)      /* bad shape / size / unsupported configuration */
@@ -147,6 +147,26 @@ int nerf_mlp_bwd_data(int model, const float* packed, int64_t M, const float* dc
                       const float* colors, const float* fwd_workspace, float* bwd_workspace, void* stream);
 int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
                          void* stream);
+
+/* ---- layer-wise dense path for the other architectures the reference's constructors accept
+ * (nerf/models.py:18-60 NeRF(pos_encoding_dim, dir_encoding_dim, hidden_dim), :148-183 Siren(...)):
+ * one nn.Linear + activation per call, any M, K, N.
+ *   forward:  y[M,N] = post * f(pre * (x[M,K] W[N,K]^T + b[N])),  f = NERF_ACT_*; x and y may be column
+ *             slices of wider matrices (row pitch ldx / ldy); aux (required for NERF_ACT_SIN, row pitch
+ *             ldy) receives post*pre*cos(pre z) for the backward.
+ *   backward: dy[M,N] (pitch lddy), the forward's y / aux (pitch ldy) and x -> dx[M,K] (pitch lddx, NULL to
+ *             skip), dW[N,K], db[N] (NULL to skip); workspace: nerf_linear_bwd_workspace_floats(M,K,N)
+ *             floats; M <= 65535*64 per call.  Reductions are ordered (no atomics). */
+#define NERF_ACT_NONE 0
+#define NERF_ACT_RELU 1
+#define NERF_ACT_SIN 2
+#define NERF_ACT_SIGMOID 3
+size_t nerf_linear_bwd_workspace_floats(int64_t M, int K, int N);
+int nerf_linear_fwd(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int K, int N, int act,
+                    double pre, double post, float* y, int64_t ldy, float* aux, void* stream);
+int nerf_linear_bwd(const float* dy, int64_t lddy, const float* y, const float* aux, int64_t ldy, int act, double pre,
+                    double post, const float* x, int64_t ldx, const float* W, int64_t M, int K, int N, float* workspace,
+                    float* dx, int64_t lddx, float* dW, float* db, void* stream);
 
 /* ---- optimizer: torch.optim.Adam as train.py:123,182 uses it (no weight decay, no amsgrad) --
  * One launch over a flat parameter buffer: p, g, m, v [n].  step is 1-based. */

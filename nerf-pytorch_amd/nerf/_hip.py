@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 MODEL_NERF = 0
 MODEL_SIREN = 1
 NUM_PARAM_TENSORS = 24
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -48,6 +48,10 @@ _SIGS = {
     "nerf_mlp_packed_bf16_bytes": (c_size_t, [c_int]),
     "nerf_mlp_pack_bf16": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
     "nerf_mlp_fwd_bf16": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P, _P, _P]),
+    "nerf_linear_bwd_workspace_floats": (c_size_t, [c_int64, c_int, c_int]),
+    "nerf_linear_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_double, c_double, _P, c_int64, _P, _P]),
+    "nerf_linear_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_double, c_double, _P, c_int64, _P, c_int64, c_int,
+                                c_int, _P, _P, c_int64, _P, _P, _P]),
     "nerf_merge_samples": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "nerf_mlp_bwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "nerf_mlp_bwd_data": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P]),
@@ -290,6 +294,40 @@ def mlp_bwd(model: int, packed: torch.Tensor, M: int, dcolors, ddensity, colors,
                                     _dev(grads, "grads"), _stream()), "nerf_mlp_bwd_weights")
     timers.stop(ev)
     return grads
+
+
+ACT_NONE, ACT_RELU, ACT_SIN, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], act: int, pre: float, post: float):
+    """y = post*f(pre*(x W^T + b)) for contiguous x [M,K], W [N,K]; returns (y, aux)."""
+    M, K = x.shape
+    N = W.shape[0]
+    if W.shape[1] != K:
+        raise ValueError(f"linear: x is [*,{K}] but W is {tuple(W.shape)}")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    aux = torch.empty((M, N), dtype=torch.float32, device=x.device) if act == ACT_SIN else None
+    ev = timers.start("linear_fwd", M)
+    _check(lib.nerf_linear_fwd(_dev(x, "x"), K, _dev(W, "W"), _opt(b, "b"), M, K, N, act, float(pre), float(post),
+                               _dev(y, "y"), N, _opt(aux, "aux"), _stream()), "nerf_linear_fwd")
+    timers.stop(ev)
+    return y, aux
+
+
+def linear_bwd(dy, y, aux, act: int, pre: float, post: float, x, W, need_dx: bool, need_db: bool):
+    M, K = x.shape
+    N = W.shape[0]
+    dev = x.device
+    ws = torch.empty(lib.nerf_linear_bwd_workspace_floats(M, K, N), dtype=torch.float32, device=dev)
+    dx = torch.empty((M, K), dtype=torch.float32, device=dev) if need_dx else None
+    dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty((N,), dtype=torch.float32, device=dev) if need_db else None
+    ev = timers.start("linear_bwd", M)
+    _check(lib.nerf_linear_bwd(_dev(dy, "dy"), N, _opt(y, "y"), _opt(aux, "aux"), N, act, float(pre), float(post),
+                               _dev(x, "x"), K, _dev(W, "W"), M, K, N, _dev(ws, "workspace"), _opt(dx, "dx"), K,
+                               _dev(dW, "dW"), _opt(db, "db"), _stream()), "nerf_linear_bwd")
+    timers.stop(ev)
+    return dx, dW, db
 
 
 def adam_step(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0) -> None:

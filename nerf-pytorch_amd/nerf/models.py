@@ -3,9 +3,9 @@
 Drop-in for the reference's nerf/models.py: same class names, constructor arguments,
 sub-module names (hence identical state_dict keys and shapes, so the reference's
 checkpoints load and torch.optim.Adam sees the same 24 tensors), same
-forward(points, rays_d) -> (colors[M,3], density[M]).  Only the architecture the
-reference's callers build (train.py:101-103, all-default arguments) has a kernel; any
-other size raises instead of silently running something else.
+forward(points, rays_d) -> (colors[M,3], density[M]).  The architecture the reference's
+callers build (train.py:101-103, all-default arguments) runs on the fused kernels; any other
+constructor arguments run layer by layer on the generic dense HIP kernels (slower, same results).
 """
 from __future__ import annotations
 
@@ -16,7 +16,13 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from .ops import MLPFunction, PackedWeights, _f32c, wants_grad
+from .ops import LinearActFunction, MLPFunction, PackedWeights, _f32c, wants_grad
+
+
+def _dense(x: torch.Tensor, lin: nn.Linear, act: int = _hip.ACT_NONE, pre: float = 1.0, post: float = 1.0,
+           rows: slice = slice(None)) -> torch.Tensor:
+    """post*f(pre*(x W^T + b)) on the layer-wise kernels; `rows` selects output rows of the layer."""
+    return LinearActFunction.apply(x, lin.weight[rows], lin.bias[rows], act, pre, post)
 
 
 def _relu_stack(dims: List[int], last_act: bool) -> nn.Sequential:
@@ -73,11 +79,18 @@ class _FusedMLP(nn.Module):
         if self._packed_bf16 is not None:
             self._packed_bf16.invalidate()
 
+    def fused_supported(self) -> bool:
+        """True when the constructor arguments are the ones the fused kernels are built for."""
+        raise NotImplementedError
+
     def _check_supported(self) -> None:
+        if not self.fused_supported():
+            raise NotImplementedError("the fused kernels cover the reference's default architecture only")
+
+    def _layerwise(self, points: torch.Tensor, rays_d: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         raise NotImplementedError
 
     def forward(self, points: torch.Tensor, rays_d: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        self._check_supported()
         if not points.is_cuda:
             raise RuntimeError("this build has no CPU path: move the model and its inputs to the HIP device "
                                "(model.to('cuda'))")
@@ -86,6 +99,8 @@ class _FusedMLP(nn.Module):
                                       "(the reference's callers never request them)")
         if points.dim() != 2 or points.shape[1] != 3 or rays_d.shape != points.shape:
             raise ValueError("points and rays_d must both be [M,3]")
+        if not self.fused_supported():
+            return self._layerwise(_f32c(points), _f32c(rays_d))
         params = self.ordered_parameters()
         train = wants_grad(params)
         return MLPFunction.apply(self.model_id, self.packed_weights(train), _f32c(points), _f32c(rays_d), train, *params)
@@ -107,10 +122,26 @@ class NeRF(_FusedMLP):
         self.pos_encoding_dim, self.dir_encoding_dim, self.hidden_dim = pos_encoding_dim, dir_encoding_dim, hidden_dim
         self._init_fused()
 
-    def _check_supported(self) -> None:
-        if (self.pos_encoding_dim, self.dir_encoding_dim, self.hidden_dim) != (10, 4, 256):
-            raise NotImplementedError("the HIP kernels cover NeRF(pos_encoding_dim=10, dir_encoding_dim=4, "
-                                      "hidden_dim=256) only")
+    def fused_supported(self) -> bool:
+        return (self.pos_encoding_dim, self.dir_encoding_dim, self.hidden_dim) == (10, 4, 256)
+
+    def _layerwise(self, points, rays_d):
+        """nerf/models.py:62-75 layer by layer; the 257-row last trunk layer is evaluated as its 256
+        feature rows (no activation) and its density row (ReLU) so that no arithmetic is left to ATen."""
+        from .encoding import positional_encoding
+        pe = positional_encoding(points, self.pos_encoding_dim)
+        de = positional_encoding(rays_d, self.dir_encoding_dim)
+        h = pe
+        for lin in self.block1[0::2]:
+            h = _dense(h, lin, _hip.ACT_RELU)
+        h = torch.cat([h, pe], dim=1)
+        trunk = list(self.block2[0::2])
+        for lin in trunk[:-1]:
+            h = _dense(h, lin, _hip.ACT_RELU)
+        feat = _dense(h, trunk[-1], _hip.ACT_NONE, rows=slice(0, self.hidden_dim))
+        density = _dense(h, trunk[-1], _hip.ACT_RELU, rows=slice(self.hidden_dim, self.hidden_dim + 1)).squeeze(-1)
+        g = _dense(torch.cat([feat, de], dim=1), self.rgb_head[0], _hip.ACT_RELU)
+        return _dense(g, self.rgb_head[2], _hip.ACT_SIGMOID), density
 
 
 class Sine(nn.Module):
@@ -167,6 +198,19 @@ class Siren(_FusedMLP):
             nn.Linear(hidden_dim // 2, 3))
         self._init_fused()
 
-    def _check_supported(self) -> None:
-        if self._cfg != (8, 256, 4, 10.0, 1.0, 30.0, 1.0):
-            raise NotImplementedError("the HIP kernels cover Siren() with the reference's default arguments only")
+    def fused_supported(self) -> bool:
+        return self._cfg == (8, 256, 4, 10.0, 1.0, 30.0, 1.0)
+
+    def _layerwise(self, points, rays_d):
+        """nerf/models.py:185-203 layer by layer (sin(w0 z), relu*sigma_mul and sigmoid(rgb_mul z) are
+        epilogues of the dense kernel)."""
+        from .encoding import positional_encoding
+        h = points
+        for layer in self.block1:
+            h = _dense(h, layer.layer, _hip.ACT_SIN, pre=layer.w0)
+        density = _dense(h, self.density_branch[0], _hip.ACT_RELU, post=self.sigma_mul).squeeze(-1)
+        feat = _dense(h, self.feature_remap[0])
+        de = positional_encoding(rays_d, self.dir_encoding_dim)
+        head = self.rgb_head[0]
+        g = _dense(torch.cat([feat, de], dim=1), head.layer, _hip.ACT_SIN, pre=head.w0)
+        return _dense(g, self.rgb_head[1], _hip.ACT_SIGMOID, pre=self.rgb_mul), density

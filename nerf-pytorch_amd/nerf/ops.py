@@ -99,6 +99,35 @@ class MLPFunction(torch.autograd.Function):
         return (None, None, None, None, None, *grads)
 
 
+class LinearActFunction(torch.autograd.Function):
+    """y = post * f(pre * (x W^T + b)): one nn.Linear + activation of an architecture that has no fused
+    kernel, forward and backward on the layer-wise HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, pre, post):
+        x, Wc = _f32c(x), _f32c(W)
+        bc = _f32c(b) if b is not None else None
+        if x.shape[0] == 0:
+            ctx.empty = True
+            return x.new_zeros((0, W.shape[0]))
+        y, aux = _hip.linear_fwd(x, Wc, bc, act, pre, post)
+        ctx.empty = False
+        ctx.cfg = (act, float(pre), float(post), b is not None)
+        ctx.save_for_backward(x, Wc, y, aux if aux is not None else y.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.empty:
+            raise RuntimeError("backward through an empty batch")
+        x, W, y, aux = ctx.saved_tensors
+        act, pre, post, has_b = ctx.cfg
+        need_dx = ctx.needs_input_grad[0]
+        dx, dW, db = _hip.linear_bwd(_f32c(dy), y, aux if aux.numel() else None, act, pre, post, x, W, need_dx,
+                                     has_b and ctx.needs_input_grad[2])
+        return dx, dW, db, None, None, None
+
+
 class RenderFunction(torch.autograd.Function):
     """rgb = composite(model(sample(rays, t))) for one ray chunk: positions are generated
     inside the MLP kernel, colors/densities go straight to the compositing kernel."""

@@ -78,7 +78,9 @@ def composite_outputs(colors: Tensor, densities: Tensor, deltas: Tensor, t: Tens
 
 
 def _fused_model(model) -> bool:
-    return hasattr(model, "model_id") and hasattr(model, "packed_weights")
+    """This package's NeRF/Siren with the architecture the fused kernels are built for; anything else
+    (other constructor arguments, foreign modules) goes through model.forward + the compositing kernel."""
+    return hasattr(model, "model_id") and hasattr(model, "packed_weights") and model.fused_supported()
 
 
 def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: float, far: float,
@@ -157,7 +159,7 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
         raise ValueError("num_coarse must be at least 3 (the PDF is built from interior coarse samples)")
     for m in (coarse, fine):
         if not _fused_model(m):
-            raise TypeError("render_nerf_hierarchical needs this package's NeRF/Siren modules")
+            raise TypeError("render_nerf_hierarchical needs this package's NeRF/Siren modules with default arguments")
         m._check_supported()
     pc, pf = coarse.ordered_parameters(), fine.ordered_parameters()
     tc_train, tf_train = wants_grad(pc), wants_grad(pf)

@@ -449,6 +449,71 @@ def test_large_batch_inference_properties(hip):
     assert rel(rgb[pick], ref) < RTOL
 
 
+# ----------------------------------------------------------------------------- other architectures
+@pytest.mark.parametrize("tag", ["nerf_h64", "siren_h64"])
+def test_model_golden_hidden64(golden, tag):
+    """hidden_dim=64 variants (nerf/models.py:21, :151 accept any width): the layer-wise dense kernels
+    against the vectors the reference produced."""
+    from nerf.models import NeRF, Siren
+    g = golden(f"g4_{tag}.npz")
+    if tag.startswith("nerf"):
+        model, params = NeRF(hidden_dim=64), O.closed_form_params(O.nerf_param_shapes(hidden=64))
+    else:
+        model, params = Siren(hidden_dim=64), O.closed_form_params(O.siren_param_shapes(hidden=64), gains=O.SIREN_GAINS)
+    model.load_state_dict(params)
+    model = model.to(DEV)
+    assert not model.fused_supported()
+    colors, dens = model(T(g["pts"]).to(DEV), T(g["dirs"]).to(DEV))
+    assert rel(colors, g["colors"]) < RTOL and rel(dens, g["density"]) < RTOL
+    (colors * T(g["gc"]).to(DEV)).sum().add((dens * T(g["gd"]).to(DEV)).sum()).backward()
+    for n, p in model.named_parameters():
+        gn = float(g["gnorm." + n])
+        assert abs(float(p.grad.norm()) - gn) <= 2e-5 * gn + 1e-9, n
+        sub = p.grad.reshape(-1)
+        step = max(1, sub.numel() // 97)
+        assert rel(sub[::step][:97], g["gsub." + n]) < 5e-5, n
+
+
+@pytest.mark.parametrize("M,K,N,act", [(1, 3, 5, 0), (70, 63, 64, 1), (257, 67, 129, 2), (1000, 131, 3, 3), (4097, 64, 1, 1)])
+def test_linear_layer_vs_torch(hip, M, K, N, act):
+    """Generic dense layer (any M, K, N) against fp32 torch on the CPU: forward and all three gradients."""
+    gen = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=gen)
+    W = torch.randn(N, K, generator=gen) / math.sqrt(K)
+    b = torch.randn(N, generator=gen) * 0.1
+    pre, post = (1.0, 1.0) if act in (0,) else (1.5, 2.0) if act in (1, 3) else (3.0, 1.0)
+    f = {0: lambda z: z, 1: lambda z: post * torch.relu(z), 2: lambda z: torch.sin(pre * z),
+         3: lambda z: post * torch.sigmoid(pre * z)}[act]
+    xr, Wr, br = (t.double().requires_grad_(True) for t in (x, W, b))
+    yr = f(xr @ Wr.t() + br)
+    gy = torch.randn(M, N, generator=gen)
+    yr.backward(gy.double())
+    from nerf.ops import LinearActFunction
+    xg, Wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, W, b))
+    y = LinearActFunction.apply(xg, Wg, bg, act, pre, post)
+    y.backward(gy.to(DEV))
+    assert rel(y, yr) < RTOL
+    for got, ref in ((xg.grad, xr.grad), (Wg.grad, Wr.grad), (bg.grad, br.grad)):
+        assert rel(got, ref) < RTOL
+
+
+def test_render_hidden64_end_to_end():
+    """render_nerf with a non-default architecture takes model.forward + the compositing kernel."""
+    from nerf.models import NeRF
+    from nerf.rendering import render_nerf
+    params = O.closed_form_params(O.nerf_param_shapes(hidden=64))
+    model = NeRF(hidden_dim=64)
+    model.load_state_dict(params)
+    model = model.to(DEV)
+    o, d = rays(40, 61)
+    u = torch.rand(32, generator=torch.Generator().manual_seed(62))
+    rgb = render_nerf(model, o.to(DEV), d.to(DEV), 2.0, 6.0, num_samples=32, device=DEV, u=[u.to(DEV)])
+    ref = O.render(lambda x, v: O.nerf_forward(params, x, v), o, d, 2.0, 6.0, 32, [u])
+    assert rel(rgb, ref) < RTOL
+    rgb.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
 # ----------------------------------------------------------------------------- bf16 opt-in mode
 BF16_VS_RESTATEMENT = 3e-3   # relative (norm-wise): same roundings, different accumulation order; a sum
                              # that lands on the other side of a bf16 rounding boundary moves one
