@@ -413,6 +413,40 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ s
     out[(size_t)row * s_row + (size_t)col * s_col] = (s0 + s1) + (s2 + s3);
 }
 
+// Same sum for slabs whose row length is a multiple of 4 and whose output has unit column stride: a
+// thread owns 4 adjacent outputs (16-byte loads) and every fourth slab, 8 loads in flight; the four
+// slab groups of a workgroup are added through LDS in a fixed order.
+__global__ __launch_bounds__(256) void reduce4_kernel(const float* __restrict__ slab, int G, int rows, int cols,
+                                                      int cols_valid, float* __restrict__ out, int s_row) {
+    __shared__ f32x4 part[4][64];
+    const int q = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i4 = blockIdx.x * 64 + q;               // index of this thread's float4 inside one slab
+    const int n4 = rows * cols / 4;
+    f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (i4 < n4) {
+        const f32x4* base = reinterpret_cast<const f32x4*>(slab) + i4;
+        const size_t stride4 = (size_t)n4;
+        int g = grp;
+        for (; g + 28 < G; g += 32) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(g + 4 * u) * stride4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u & 1] += v[u];
+        }
+        for (; g < G; g += 4) s[0] += base[(size_t)g * stride4];
+    }
+    part[grp][q] = s[0] + s[1];
+    __syncthreads();
+    if (grp == 0 && i4 < n4) {
+        const f32x4 t = (part[0][q] + part[1][q]) + (part[2][q] + part[3][q]);
+        const int row = (4 * i4) / cols, col = 4 * i4 - row * cols;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < cols_valid) out[(size_t)row * s_row + col + e] = t[e];
+    }
+}
+
 template <typename K>
 int set_lds(K kernel, int bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -429,7 +463,10 @@ struct Ctx {
 
 void reduce(Ctx& c, const float* slab, int G, int rows, int cols, int cols_valid, float* out, int s_row, int s_col) {
     if (c.rc) return;
-    reduce_kernel<<<(rows * cols + 255) / 256, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, s_col);
+    if (s_col == 1 && cols % 4 == 0 && rows * cols >= 4096)
+        reduce4_kernel<<<(rows * cols / 4 + 63) / 64, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row);
+    else
+        reduce_kernel<<<(rows * cols + 255) / 256, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, s_col);
     c.rc = nerf_check_launch("wgrad reduce");
 }
 
