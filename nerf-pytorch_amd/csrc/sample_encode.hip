@@ -293,20 +293,27 @@ extern "C" int nerf_compute_rays(const float* c2w, int64_t N, int H, int W, doub
 // ---------------------------------------------------------------------------------------
 // sorted union of the shared coarse depths and each ray's fine depths (canonical NeRF:
 // sort(cat(z_vals, z_samples))) plus the successive differences the compositor needs.
-// One ray per wavefront, bitonic sort of the padded (+inf) sequence in LDS.
+// One ray per wavefront.  The coarse depths are already ascending, so only the ray's fine depths are
+// sorted (bitonic, padded with +inf, in LDS); every element then finds its place in the union by a
+// binary search in the OTHER list: fine[i] goes to i + #{coarse <= fine[i]}, coarse[j] to
+// j + #{fine < coarse[j]}.  A wave only touches its own LDS rows and LDS operations of one wave are
+// carried out in program order, so the stages are separated by wave-level scheduling barriers only.
 // ---------------------------------------------------------------------------------------
 #define MERGE_MAX 1024
 __global__ __launch_bounds__(256) void merge_samples_kernel(const float* __restrict__ tc, const float* __restrict__ tf,
                                                            int64_t R, int Sc, int Sf, int N, float* __restrict__ t_all,
                                                            float* __restrict__ deltas) {
-    __shared__ float buf[4][MERGE_MAX];
+    extern __shared__ float merge_lds[];   // per wave: fine [N] | coarse [Sc] | union [Sc+Sf]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     const int64_t rr = r < R ? r : R - 1;  // out-of-range waves redo the last ray and store nothing
-    float* b = buf[wv];
     const int S = Sc + Sf;
-    for (int i = lane; i < N; i += 64) b[i] = i < Sc ? tc[i] : (i < S ? tf[rr * Sf + (i - Sc)] : INFINITY);
-    __syncthreads();
+    float* b = merge_lds + (size_t)wv * (N + Sc + S);
+    float* c = b + N;
+    float* o = c + Sc;
+    for (int i = lane; i < N; i += 64) b[i] = i < Sf ? tf[rr * Sf + i] : INFINITY;
+    for (int i = lane; i < Sc; i += 64) c[i] = tc[i];
+    __builtin_amdgcn_wave_barrier();
     for (int k = 2; k <= N; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = lane; i < N; i += 64) {
@@ -317,12 +324,31 @@ __global__ __launch_bounds__(256) void merge_samples_kernel(const float* __restr
                     if ((x > y) == up) { b[i] = y; b[p] = x; }
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
+    for (int i = lane; i < Sf; i += 64) {       // #{coarse <= v}: first index with coarse > v
+        const float v = b[i];
+        int lo = 0, hi = Sc;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (c[mid] <= v) lo = mid + 1; else hi = mid;
+        }
+        o[i + lo] = v;
+    }
+    for (int j = lane; j < Sc; j += 64) {       // #{fine < v}: first index with fine >= v
+        const float v = c[j];
+        int lo = 0, hi = Sf;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (b[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        o[j + lo] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
     if (r < R)
         for (int i = lane; i < S; i += 64) {
-            t_all[r * S + i] = b[i];
-            deltas[r * S + i] = (i + 1 < S) ? sub_rn(b[i + 1], b[i]) : 1e10f;
+            t_all[r * S + i] = o[i];
+            deltas[r * S + i] = (i + 1 < S) ? sub_rn(o[i + 1], o[i]) : 1e10f;
         }
 }
 
@@ -335,9 +361,10 @@ extern "C" int nerf_merge_samples(const float* t_coarse, const float* t_fine, in
     if (Sf > 0) NERF_REQUIRE_PTR(t_fine);
     NERF_REQUIRE_PTR(t_all);
     NERF_REQUIRE_PTR(deltas);
-    int N = 2;
-    while (N < Sc + Sf) N <<= 1;
-    merge_samples_kernel<<<(unsigned)ceil_div64(R, 4), 256, 0, (hipStream_t)stream>>>(t_coarse, t_fine, R, Sc, Sf, N,
-                                                                                     t_all, deltas);
+    int N = 2;   // bitonic length: the fine depths padded to a power of two
+    while (N < Sf) N <<= 1;
+    const size_t lds = 4 * (size_t)(N + 2 * Sc + Sf) * sizeof(float);   // at most 4 * 3072 * 4 = 48 KiB
+    merge_samples_kernel<<<(unsigned)ceil_div64(R, 4), 256, lds, (hipStream_t)stream>>>(t_coarse, t_fine, R, Sc, Sf, N,
+                                                                                       t_all, deltas);
     return nerf_check_launch("nerf_merge_samples");
 }
