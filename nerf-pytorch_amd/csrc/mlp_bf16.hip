@@ -29,6 +29,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int UNIT_BYTES = 1024;     // one A fragment for a whole wave
 constexpr int CHUNK_UNITS = 32;
@@ -153,44 +154,63 @@ struct Bf16Args {
     float nearf, spanf;
     float* colors;
     float* density;
+#ifdef NERF_DIAG
+    unsigned long long* dbg;   // [workgroup][32] shader-clock stamps
+#endif
 };
+
+#ifdef NERF_DIAG
+#define DIAG_STAMP(i)                                                                          \
+    do {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#else
+#define DIAG_STAMP(i) ((void)0)
+#endif
 
 constexpr int BF16_LDS_BYTES = NBUF * CHUNK_BYTES + (int)BIAS_FLOATS * 4;
 
 struct Ring {
     const unsigned char* img;
     unsigned char* lds;
-    int next;   // chunk the next acquire publishes
+    int next;   // chunk the next begin_chunk() hands out
     int tid, wave;
 };
+constexpr int PER_CHUNK = CHUNK_BYTES / (16 * WG_THREADS);   // global_load_lds instructions per thread and chunk
 
 __device__ __forceinline__ void ring_issue(const Ring& r, int chunk) {
     if (chunk < NCHUNK) {
         const unsigned char* src = r.img + (size_t)chunk * CHUNK_BYTES + 16 * r.tid;
         unsigned char* dst = r.lds + (chunk & (NBUF - 1)) * CHUNK_BYTES + 16 * 64 * r.wave;
 #pragma unroll
-        for (int i = 0; i < CHUNK_BYTES / (16 * WG_THREADS); ++i)
+        for (int i = 0; i < PER_CHUNK; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 16 * WG_THREADS),
                                              (__attribute__((address_space(3))) void*)(dst + i * 16 * WG_THREADS), 16, 0, 0);
     }
 }
 
-// Publish the next chunk: wait until this thread's pieces of it have landed (AHEAD chunks issued
-// after it may stay in flight), meet the other waves (their pieces have landed too, and everyone is
-// done reading the previous chunk), then refill the previous chunk's buffer.
-template <int AHEAD>
-__device__ __forceinline__ const unsigned char* ring_acquire(Ring& r) {
-    constexpr int PER_CHUNK = CHUNK_BYTES / (16 * WG_THREADS);
-    if constexpr (AHEAD >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_CHUNK) : "memory");
-    else if constexpr (AHEAD == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the previous chunk have returned
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    ring_issue(r, r.next + NBUF - 1);
+// Ring protocol.  While the waves read chunk c (already published), chunk c+1 is published a few
+// units into c: every wave waits for its own pieces of c+1 (counted vmcnt: c+2 may stay in flight),
+// all waves meet at one barrier, and the buffer of chunk c-1 -- which no wave can still be reading,
+// each having consumed at least one unit of c -- is refilled with chunk c+3.  The fragment reads of
+// chunk c that are in flight at the barrier are untouched by it, so the MFMA stream never drains.
+__device__ __forceinline__ const unsigned char* ring_begin_chunk(Ring& r) {
     const unsigned char* buf = r.lds + (r.next & (NBUF - 1)) * CHUNK_BYTES;
     ++r.next;
     return buf;
+}
+// REM = chunks of the whole stream that follow the one being read (2 = two or more)
+template <int REM>
+__device__ __forceinline__ void ring_publish_next(Ring& r) {
+    if constexpr (REM >= 1) {
+        if constexpr (REM >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ring_issue(r, r.next + 2);   // r.next is the chunk just published
+    }
 }
 
 template <int NOT>
@@ -226,15 +246,17 @@ template <int NOT, int NKS_A, int NKS_E, int TAIL>
 __device__ __forceinline__ void mma_layer16(Ring& r, int lane, f32x16 (&acc)[9], const bf16x8 (&XA)[16],
                                             const bf16x8 (&XE)[4]) {
     constexpr int NKS = NKS_A + NKS_E, UNITS = NOT * NKS, CHUNKS = (UNITS + CHUNK_UNITS - 1) / CHUNK_UNITS;
-    constexpr int PF = 4;
-    static_assert(UNITS >= PF, "layer shorter than the prefetch distance");
+    constexpr int PF = 4;            // fragment reads in flight
+    constexpr int PUBLISH_AT = PF;   // unit of a chunk at whose fetch the next chunk is published
+    static_assert(UNITS >= PF && (UNITS % CHUNK_UNITS == 0 || UNITS % CHUNK_UNITS > PUBLISH_AT), "chunk too short");
     const unsigned char* buf = nullptr;
     bf16x8 a[PF];
     auto fetch = [&](auto U) {
         constexpr int u = decltype(U)::value;
-        if constexpr (u % CHUNK_UNITS == 0) {
-            constexpr int left = (CHUNKS - 1 - u / CHUNK_UNITS) + TAIL;
-            buf = ring_acquire<(left >= 2 ? 2 : left)>(r) + 16 * lane;
+        if constexpr (u % CHUNK_UNITS == 0) buf = ring_begin_chunk(r) + 16 * lane;
+        if constexpr (u % CHUNK_UNITS == PUBLISH_AT) {
+            constexpr int rem = (CHUNKS - 1 - u / CHUNK_UNITS) + TAIL;
+            ring_publish_next<(rem >= 2 ? 2 : rem)>(r);
         }
         a[u % PF] = *reinterpret_cast<const bf16x8*>(buf + (u % CHUNK_UNITS) * UNIT_BYTES);
     };
@@ -265,12 +287,10 @@ __device__ __forceinline__ void to_frags(const f32x16 (&acc)[9], bf16x8* X) {
             u32x4 w;
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) {
-                float v0 = acc[ft][8 * s + 2 * jp], v1 = acc[ft][8 * s + 2 * jp + 1];
-                if (RELU) {
-                    v0 = fmaxf(v0, 0.0f);
-                    v1 = fmaxf(v1, 0.0f);
-                }
-                w[jp] = pack2(v0, v1);
+                // ReLU on the packed pair: as 16-bit integers, negative bf16 values are negative
+                const unsigned pk = pack2(acc[ft][8 * s + 2 * jp], acc[ft][8 * s + 2 * jp + 1]);
+                w[jp] = RELU ? __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), s16x2{0, 0}))
+                             : pk;
             }
             X[2 * ft + s] = __builtin_bit_cast(bf16x8, w);
         }
@@ -287,6 +307,19 @@ __device__ __forceinline__ void vals_to_frags(const float (&v)[N], bf16x8* X) {
     }
 }
 
+// sin/cos of s0*2^f*x for f = 0..NF-1: one accurate sincos at the base frequency, then angle
+// doubling (sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a).  The absolute error doubles per step:
+// about 1e-6 after four steps, three orders below half a bf16 ulp of the values it feeds.
+template <int NF>
+__device__ __forceinline__ void sincos_octaves(float base_arg, float (&sn)[NF], float (&cs)[NF]) {
+    nerf_sincosf(base_arg, &sn[0], &cs[0]);
+#pragma unroll
+    for (int f = 1; f < NF; ++f) {
+        sn[f] = 2.0f * sn[f - 1] * cs[f - 1];
+        cs[f] = fmaf(-2.0f * sn[f - 1], sn[f - 1], 1.0f);
+    }
+}
+
 __device__ __forceinline__ float norm_coord16(float p, float nearf, float spanf) {
 #pragma clang fp contract(off)  // same operation order and rounding as the fp32 path
     return sub_rn(div_rn(mul_rn(2.0f, sub_rn(p, nearf)), spanf), 1.0f);
@@ -299,11 +332,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
 
-    Ring ring{a.img, smem, 0, tid, wave};
-    ring_issue(ring, 0);
-    ring_issue(ring, 1);
-    ring_issue(ring, 2);
-
+    DIAG_STAMP(0);
+    // Ordinary loads first (inputs, bias image -> LDS): once LDS-DMA loads are in flight the compiler
+    // waits for ALL of them at the first use of an ordinary load's result.
     const float* bias_g = reinterpret_cast<const float*>(a.img + IMG_BYTES);
     for (int i = tid; i < (int)BIAS_FLOATS; i += WG_THREADS) bias_lds[i] = bias_g[i];
 
@@ -329,6 +360,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing ordinary is outstanding from here on
+    __builtin_amdgcn_sched_barrier(0);
+    Ring ring{a.img, smem, 0, tid, wave};
+    ring_issue(ring, 0);   // these land while the encodings below are computed
+    ring_issue(ring, 1);
+    ring_issue(ring, 2);
+    __builtin_amdgcn_sched_barrier(0);
 
     // encodings in the slot order k_column() gives the weight image: half h owns frequencies
     // 5h..5h+4 of the position and 2h..2h+1 of the direction, the raw coordinates fill the tail
@@ -337,19 +375,25 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
         float v[32];
         const float s0 = h ? 32.0f : 1.0f;
 #pragma unroll
-        for (int f = 0; f < 5; ++f)
+        for (int c = 0; c < 3; ++c) {
+            float sn[5], cs[5];
+            sincos_octaves<5>(mul_rn(s0, x[c]), sn, cs);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float sn, cs;
-                nerf_sincosf(mul_rn(s0 * (float)(1 << f), x[c]), &sn, &cs);
-                v[6 * f + c] = sn;
-                v[6 * f + 3 + c] = cs;
+            for (int f = 0; f < 5; ++f) {
+                v[6 * f + c] = sn[f];
+                v[6 * f + 3 + c] = cs[f];
             }
+        }
         v[30] = h ? x[2] : x[0];
         v[31] = h ? 0.0f : x[1];
         vals_to_frags<32>(v, PE);
     }
-    __syncthreads();  // bias image visible
+    // publish chunk 0 and the bias image: own pieces of chunk 0 landed (chunks 1, 2 stay in flight),
+    // own LDS writes done, then the barrier
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER_CHUNK) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    DIAG_STAMP(1);
 
     f32x16 acc[9];
     bf16x8 X[16];
@@ -357,12 +401,17 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
     init_bias<8>(acc, bias_lds, bias_tile0(0), h);
     mma_layer16<8, 0, 4, 2>(ring, lane, acc, X, PE);
     to_frags<8, true>(acc, X);
+    DIAG_STAMP(2);
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
         init_bias<8>(acc, bias_lds, 8 * l, h);
+        DIAG_STAMP(10 + 3 * (l - 1));
         mma_layer16<8, 16, 0, 2>(ring, lane, acc, X, PE);
+        DIAG_STAMP(11 + 3 * (l - 1));
         to_frags<8, true>(acc, X);
+        DIAG_STAMP(12 + 3 * (l - 1));
     }
+    DIAG_STAMP(3);
     // skip layer: [features | position encoding]
     init_bias<8>(acc, bias_lds, bias_tile0(5), h);
     mma_layer16<8, 16, 4, 2>(ring, lane, acc, X, PE);
@@ -385,14 +434,15 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
         float v[16];
         const float s0 = h ? 4.0f : 1.0f;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int c = 0; c < 3; ++c) {
+            float sn[2], cs[2];
+            sincos_octaves<2>(mul_rn(s0, d[c]), sn, cs);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float sn, cs;
-                nerf_sincosf(mul_rn(s0 * (float)(1 << f), d[c]), &sn, &cs);
-                v[6 * f + c] = sn;
-                v[6 * f + 3 + c] = cs;
+            for (int f = 0; f < 2; ++f) {
+                v[6 * f + c] = sn[f];
+                v[6 * f + 3 + c] = cs[f];
             }
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[12 + c] = h ? 0.0f : d[c];
         v[15] = 0.0f;
@@ -404,14 +454,21 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
     init_bias<1>(acc, bias_lds, bias_tile0(11), h);
     mma_layer16<1, 8, 0, 0>(ring, lane, acc, X, DE);
 
+    DIAG_STAMP(4);
     if (valid && h == 0) {  // rows 0..2 of the last tile and the density row sit in lane half 0
 #pragma unroll
         for (int c = 0; c < 3; ++c) a.colors[m * 3 + c] = dev::sigmoidf_(acc[0][c]);
         a.density[m] = dens;
     }
+    DIAG_STAMP(5);
 }
 
 }  // namespace
+
+#ifdef NERF_DIAG
+static unsigned long long* g_bf16_dbg = nullptr;
+extern "C" void nerf_diag_bf16_stamps(unsigned long long* device_buffer) { g_bf16_dbg = device_buffer; }
+#endif
 
 extern "C" size_t nerf_mlp_packed_bf16_bytes(int model) { return model == NERF_MODEL_NERF ? PACKED_BYTES : 0; }
 
@@ -456,7 +513,11 @@ extern "C" int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const
     const int64_t groups = ceil_div64(M, WG_SAMPLES);
     NERF_REQUIRE(groups < (1ll << 31), "nerf_mlp_fwd_bf16: too many samples");
     Bf16Args a{static_cast<const unsigned char*>(packed), M, points, dirs, rays_o, rays_d, t, S, t_per_ray,
-               (float)near, (float)(far - near), colors, density};
+               (float)near, (float)(far - near), colors, density
+#ifdef NERF_DIAG
+               , g_bf16_dbg
+#endif
+    };
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_fwd_bf16_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, BF16_LDS_BYTES);
     if (e != hipSuccess) return nerf_fail(NERF_E_LAUNCH, "nerf_mlp_fwd_bf16: LDS attribute: %s", hipGetErrorString(e));
