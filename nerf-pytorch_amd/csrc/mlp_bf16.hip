@@ -175,19 +175,25 @@ constexpr int BF16_LDS_BYTES = NBUF * CHUNK_BYTES + (int)BIAS_FLOATS * 4;
 struct Ring {
     const unsigned char* img;
     unsigned char* lds;
-    int next;   // chunk the next begin_chunk() hands out
-    int tid, wave;
+    int next;        // chunk the next begin_chunk() hands out
+    unsigned voff;   // this thread's byte offset inside a 8 KiB slice of a chunk (16 * tid)
+    int wave;
 };
 constexpr int PER_CHUNK = CHUNK_BYTES / (16 * WG_THREADS);   // global_load_lds instructions per thread and chunk
 
 __device__ __forceinline__ void ring_issue(const Ring& r, int chunk) {
     if (chunk < NCHUNK) {
-        const unsigned char* src = r.img + (size_t)chunk * CHUNK_BYTES + 16 * r.tid;
+        // uniform 64-bit base + 32-bit per-thread offset: the address needs one VGPR, not a pair per chunk
+        const unsigned long long base = reinterpret_cast<unsigned long long>(r.img) + (unsigned long long)chunk * CHUNK_BYTES;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(
+            ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)base));
         unsigned char* dst = r.lds + (chunk & (NBUF - 1)) * CHUNK_BYTES + 16 * 64 * r.wave;
 #pragma unroll
         for (int i = 0; i < PER_CHUNK; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 16 * WG_THREADS),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 16 * WG_THREADS), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + i * 16 * WG_THREADS + r.voff),
+                (__attribute__((address_space(3))) void*)(dst + i * 16 * WG_THREADS), 16, 0, 0);
     }
 }
 
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing ordinary is outstanding from here on
     __builtin_amdgcn_sched_barrier(0);
-    Ring ring{a.img, smem, 0, tid, wave};
+    Ring ring{a.img, smem, 0, 16u * (unsigned)tid, wave};
     ring_issue(ring, 0);   // these land while the encodings below are computed
     ring_issue(ring, 1);
     ring_issue(ring, 2);
