@@ -8,8 +8,15 @@ from nerf.models import NeRF
 m = NeRF().cuda()
 R, S = 4096, 256
 M = R * S
-o = torch.randn(R, 3, device="cuda"); d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda"), dim=1)
-t = torch.linspace(2, 6, S, device="cuda")
+if len(sys.argv) > 1 and sys.argv[1] == "scene":   # the benchmark's rays and a stratified draw instead of random ones
+    import bench
+    ro, rd, _ = bench.make_rays(2, 800, 800, torch.device("cuda"), seed=42)
+    idx = torch.randint(0, ro.shape[0], (R,), device="cuda")
+    o, d = ro[idx].contiguous(), rd[idx].contiguous()
+    t, _ = _hip.stratified_t(2.0, 6.0, S, torch.rand(S, device="cuda"))
+else:
+    o = torch.randn(R, 3, device="cuda"); d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda"), dim=1)
+    t = torch.linspace(2, 6, S, device="cuda")
 packed = m.packed_weights()
 colors = torch.empty(M, 3, device="cuda"); dens = torch.empty(M, device="cuda")
 ws = torch.empty(_hip.lib.nerf_mlp_fwd_workspace_floats(0, M), device="cuda")
