@@ -447,6 +447,32 @@ __global__ __launch_bounds__(256) void reduce4_kernel(const float* __restrict__ 
     }
 }
 
+// Small outputs (bias vectors, the rank-1 row, the thin products): the sum over slabs is what takes
+// time, so 32 lanes share one output, each adding every 32nd slab (independent loads), and a
+// half-wave butterfly in a fixed order finishes it.
+__global__ __launch_bounds__(256) void reduce_small_kernel(const float* __restrict__ slab, int G, int rows, int cols,
+                                                           int cols_valid, float* __restrict__ out, int s_row, int s_col) {
+    const int j = threadIdx.x & 31;
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int n = rows * cols;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int g = j;
+        for (; g + 32 < G; g += 64) {
+            s0 += slab[(size_t)g * n + i];
+            s1 += slab[(size_t)(g + 32) * n + i];
+        }
+        if (g < G) s0 += slab[(size_t)g * n + i];
+    }
+    float s = s0 + s1;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (j == 0 && i < n) {
+        const int row = i / cols, col = i - row * cols;
+        if (col < cols_valid) out[(size_t)row * s_row + (size_t)col * s_col] = s;
+    }
+}
+
 template <typename K>
 int set_lds(K kernel, int bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -463,7 +489,9 @@ struct Ctx {
 
 void reduce(Ctx& c, const float* slab, int G, int rows, int cols, int cols_valid, float* out, int s_row, int s_col) {
     if (c.rc) return;
-    if (s_col == 1 && cols % 4 == 0 && rows * cols >= 4096)
+    if (rows * cols < 4096)
+        reduce_small_kernel<<<(rows * cols + 7) / 8, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, s_col);
+    else if (s_col == 1 && cols % 4 == 0)
         reduce4_kernel<<<(rows * cols / 4 + 63) / 64, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row);
     else
         reduce_kernel<<<(rows * cols + 255) / 256, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, s_col);
