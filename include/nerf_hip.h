@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 4
+#define NERF_ABI_VERSION 5
 
 #define NERF_OK 0
 #define NERF_E_ARG (-1)      /* bad shape / size / unsupported configuration */
@@ -133,11 +133,12 @@ int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const float* poi
 /* Backward of nerf_mlp_fwd wrt the 24 parameter tensors.
  * dcolors [M,3], ddensity [M]: upstream gradients; colors: the forward's output.
  * grads: flat buffer of nerf_mlp_param_floats(model) floats, tensors laid out back to back
- * in state_dict order (OVERWRITTEN, not accumulated).
+ * in state_dict order; accumulate == 0: overwritten, != 0: added to (as autograd does when several
+ * ray chunks contribute to one optimizer step).
  * bwd_workspace: nerf_mlp_bwd_workspace_floats(model, M) floats of scratch. */
 int nerf_mlp_bwd(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
                  const float* colors, const float* fwd_workspace, float* bwd_workspace, float* grads,
-                 void* stream);
+                 int accumulate, void* stream);
 
 /* The two stages of nerf_mlp_bwd, callable separately (nerf_mlp_bwd = data then weights):
  *   _data:    fused per-tile data-gradient chain; fills bwd_workspace with every layer's dY;
@@ -146,7 +147,7 @@ int nerf_mlp_bwd(int model, const float* packed, int64_t M, const float* dcolors
 int nerf_mlp_bwd_data(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
                       const float* colors, const float* fwd_workspace, float* bwd_workspace, void* stream);
 int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
-                         void* stream);
+                         int accumulate, void* stream);
 
 /* ---- layer-wise dense path for the other architectures the reference's constructors accept
  * (nerf/models.py:18-60 NeRF(pos_encoding_dim, dir_encoding_dim, hidden_dim), :148-183 Siren(...)):

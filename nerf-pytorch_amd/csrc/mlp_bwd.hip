@@ -394,8 +394,9 @@ __global__ __launch_bounds__(256) void thin_kernel(ThinArgs a) {
 }
 
 // out[row*s_row + col*s_col] = sum_g slab[g][row][col], row < rows, col < cols_valid
+// acc != 0: the sum is added to what `out` holds (gradient accumulation across calls)
 __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ slab, int G, int rows, int cols,
-                                                     int cols_valid, float* __restrict__ out, int s_row, int s_col) {
+                                                     int cols_valid, float* __restrict__ out, int s_row, int s_col, int acc) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * cols) return;
     const int row = i / cols, col = i - row * cols;
@@ -410,14 +411,15 @@ __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ s
         s3 += slab[(size_t)(g + 3) * stride + i];
     }
     for (; g < G; ++g) s0 += slab[(size_t)g * stride + i];
-    out[(size_t)row * s_row + (size_t)col * s_col] = (s0 + s1) + (s2 + s3);
+    float* o = out + (size_t)row * s_row + (size_t)col * s_col;
+    *o = (acc ? *o : 0.0f) + ((s0 + s1) + (s2 + s3));
 }
 
 // Same sum for slabs whose row length is a multiple of 4 and whose output has unit column stride: a
 // thread owns 4 adjacent outputs (16-byte loads) and every fourth slab, 8 loads in flight; the four
 // slab groups of a workgroup are added through LDS in a fixed order.
 __global__ __launch_bounds__(256) void reduce4_kernel(const float* __restrict__ slab, int G, int rows, int cols,
-                                                      int cols_valid, float* __restrict__ out, int s_row) {
+                                                      int cols_valid, float* __restrict__ out, int s_row, int acc) {
     __shared__ f32x4 part[4][64];
     const int q = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int i4 = blockIdx.x * 64 + q;               // index of this thread's float4 inside one slab
@@ -443,7 +445,10 @@ __global__ __launch_bounds__(256) void reduce4_kernel(const float* __restrict__ 
         const int row = (4 * i4) / cols, col = 4 * i4 - row * cols;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (col + e < cols_valid) out[(size_t)row * s_row + col + e] = t[e];
+            if (col + e < cols_valid) {
+                float* o = out + (size_t)row * s_row + col + e;
+                *o = (acc ? *o : 0.0f) + t[e];
+            }
     }
 }
 
@@ -451,7 +456,8 @@ __global__ __launch_bounds__(256) void reduce4_kernel(const float* __restrict__ 
 // time, so 32 lanes share one output, each adding every 32nd slab (independent loads), and a
 // half-wave butterfly in a fixed order finishes it.
 __global__ __launch_bounds__(256) void reduce_small_kernel(const float* __restrict__ slab, int G, int rows, int cols,
-                                                           int cols_valid, float* __restrict__ out, int s_row, int s_col) {
+                                                           int cols_valid, float* __restrict__ out, int s_row, int s_col,
+                                                           int acc) {
     const int j = threadIdx.x & 31;
     const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int n = rows * cols;
@@ -469,7 +475,10 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(const float* __restri
     for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (j == 0 && i < n) {
         const int row = i / cols, col = i - row * cols;
-        if (col < cols_valid) out[(size_t)row * s_row + (size_t)col * s_col] = s;
+        if (col < cols_valid) {
+            float* o = out + (size_t)row * s_row + (size_t)col * s_col;
+            *o = (acc ? *o : 0.0f) + s;
+        }
     }
 }
 
@@ -485,16 +494,19 @@ struct Ctx {
     size_t Mp;
     float* slab;   // SLAB_FLOATS
     int rc;
+    int accumulate;   // add to the gradient buffer instead of overwriting it
 };
 
 void reduce(Ctx& c, const float* slab, int G, int rows, int cols, int cols_valid, float* out, int s_row, int s_col) {
     if (c.rc) return;
     if (rows * cols < 4096)
-        reduce_small_kernel<<<(rows * cols + 7) / 8, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, s_col);
+        reduce_small_kernel<<<(rows * cols + 7) / 8, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, s_col,
+                                                                          c.accumulate);
     else if (s_col == 1 && cols % 4 == 0)
-        reduce4_kernel<<<(rows * cols / 4 + 63) / 64, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row);
+        reduce4_kernel<<<(rows * cols / 4 + 63) / 64, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, c.accumulate);
     else
-        reduce_kernel<<<(rows * cols + 255) / 256, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, s_col);
+        reduce_kernel<<<(rows * cols + 255) / 256, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, s_col,
+                                                                   c.accumulate);
     c.rc = nerf_check_launch("wgrad reduce");
 }
 
@@ -578,7 +590,7 @@ extern "C" int nerf_mlp_bwd_data(int model, const float* packed, int64_t M, cons
 }
 
 extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
-                                    void* stream) {
+                                    int accumulate, void* stream) {
     using namespace lay;
     int rc;
     if ((rc = bwd_check_args("nerf_mlp_bwd_weights", model, grads, M, fwd_workspace, bwd_workspace))) return rc;
@@ -588,7 +600,7 @@ extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_works
     float* bw = bwd_workspace;
     if (model == NERF_MODEL_NERF) {
         using namespace lay::nerf;
-        Ctx c{st, Mp, bw + BW_PER_SAMPLE * Mp, 0};
+        Ctx c{st, Mp, bw + BW_PER_SAMPLE * Mp, 0, accumulate != 0};
         auto W = [&](int layer) { return grads + param_off(2 * layer); };
         auto B = [&](int layer) { return grads + param_off(2 * layer + 1); };
         auto h = [&](int l) { return ws + (WS_H + (size_t)l * H) * Mp; };
@@ -609,7 +621,7 @@ extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_works
         return c.rc;
     } else {
         using namespace lay::siren;
-        Ctx c{st, Mp, bw + BW_PER_SAMPLE * Mp, 0};
+        Ctx c{st, Mp, bw + BW_PER_SAMPLE * Mp, 0, accumulate != 0};
         auto W = [&](int layer) { return grads + param_off(2 * layer); };
         auto B = [&](int layer) { return grads + param_off(2 * layer + 1); };
         auto h = [&](int l) { return ws + (WS_H + (size_t)l * H) * Mp; };
@@ -628,11 +640,11 @@ extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_works
 
 extern "C" int nerf_mlp_bwd(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
                             const float* colors, const float* fwd_workspace, float* bwd_workspace, float* grads,
-                            void* stream) {
+                            int accumulate, void* stream) {
     NERF_REQUIRE_PTR(grads);
     int rc = nerf_mlp_bwd_data(model, packed, M, dcolors, ddensity, colors, fwd_workspace, bwd_workspace, stream);
     if (rc) return rc;
-    return nerf_mlp_bwd_weights(model, M, fwd_workspace, bwd_workspace, grads, stream);
+    return nerf_mlp_bwd_weights(model, M, fwd_workspace, bwd_workspace, grads, accumulate, stream);
 }
 
 // =====================================================================================

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 MODEL_NERF = 0
 MODEL_SIREN = 1
 NUM_PARAM_TENSORS = 24
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -53,9 +53,9 @@ _SIGS = {
     "nerf_linear_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_double, c_double, _P, c_int64, _P, c_int64, c_int,
                                 c_int, _P, _P, c_int64, _P, _P, _P]),
     "nerf_merge_samples": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),
-    "nerf_mlp_bwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "nerf_mlp_bwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "nerf_mlp_bwd_data": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P]),
-    "nerf_mlp_bwd_weights": (c_int, [c_int, c_int64, _P, _P, _P, _P]),
+    "nerf_mlp_bwd_weights": (c_int, [c_int, c_int64, _P, _P, _P, c_int, _P]),
     "nerf_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_double, c_double, c_double, c_double, c_double, _P]),
     "nerf_weights_to_cdf": (c_int, [_P, c_int64, c_int, _P, _P]),
     "nerf_sample_pdf": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
@@ -279,10 +279,15 @@ def mlp_fwd_bf16(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=
     return colors, density, None
 
 
-def mlp_bwd(model: int, packed: torch.Tensor, M: int, dcolors, ddensity, colors, ws, grads: Optional[torch.Tensor] = None):
+def mlp_bwd(model: int, packed: torch.Tensor, M: int, dcolors, ddensity, colors, ws, grads: Optional[torch.Tensor] = None,
+            accumulate: bool = False):
+    """Flat parameter gradient (state_dict order).  With `grads` given and accumulate=True the result is
+    added to that buffer (the optimizer's bucket) instead of a fresh one."""
     dev = packed.device
     if grads is None:
         grads = torch.empty(param_floats(model), dtype=torch.float32, device=dev)
+    elif grads.dim() != 1 or grads.numel() != param_floats(model):
+        raise ValueError(f"gradient buffer must be a flat tensor of {param_floats(model)} floats, got {tuple(grads.shape)}")
     bw = torch.empty(lib.nerf_mlp_bwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
     ev = timers.start("mlp_bwd_data", M)
     _check(lib.nerf_mlp_bwd_data(model, _dev(packed, "packed"), M, _dev(dcolors, "dcolors"), _dev(ddensity, "ddensity"),
@@ -291,7 +296,7 @@ def mlp_bwd(model: int, packed: torch.Tensor, M: int, dcolors, ddensity, colors,
     timers.stop(ev)
     ev = timers.start("mlp_bwd_weights", M)
     _check(lib.nerf_mlp_bwd_weights(model, M, _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
-                                    _dev(grads, "grads"), _stream()), "nerf_mlp_bwd_weights")
+                                    _dev(grads, "grads"), int(bool(accumulate)), _stream()), "nerf_mlp_bwd_weights")
     timers.stop(ev)
     return grads
 

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from .ops import LinearActFunction, MLPFunction, PackedWeights, _f32c, wants_grad
+from .ops import LinearActFunction, MLPFunction, PackedWeights, _f32c, grad_sink, wants_grad
 
 
 def _dense(x: torch.Tensor, lin: nn.Linear, act: int = _hip.ACT_NONE, pre: float = 1.0, post: float = 1.0,
@@ -103,7 +103,8 @@ class _FusedMLP(nn.Module):
             return self._layerwise(_f32c(points), _f32c(rays_d))
         params = self.ordered_parameters()
         train = wants_grad(params)
-        return MLPFunction.apply(self.model_id, self.packed_weights(train), _f32c(points), _f32c(rays_d), train, *params)
+        return MLPFunction.apply(self.model_id, self.packed_weights(train), _f32c(points), _f32c(rays_d), train,
+                                 grad_sink(self, params) if train else None, *params)
 
 
 class NeRF(_FusedMLP):

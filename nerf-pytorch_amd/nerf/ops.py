@@ -55,13 +55,36 @@ def _mlp_fwd(model_id, packed, M, train, **inputs):
     return _hip.mlp_fwd(model_id, packed, M, train=train, **inputs)
 
 
-def _split_grads(flat: torch.Tensor, params: Sequence[torch.Tensor]):
-    out, off = [], 0
-    for p in params:
-        n = p.numel()
-        out.append(flat[off:off + n].view(p.shape))
+def grad_sink(module, params: Sequence[torch.Tensor]):
+    """The module's flat gradient bucket (set by parallel.FlatParameters) if the parameters' .grad are
+    still views of it; the backward kernels then add into the bucket directly and autograd is handed
+    no per-tensor gradients (no 24 accumulation kernels, no temporary)."""
+    sink = getattr(module, "_grad_sink", None)
+    if sink is None or not params:
+        return None
+    g = params[0].grad
+    if g is None or g.data_ptr() != sink.data_ptr() or sink.device != params[0].device:
+        return None
+    return sink
+
+
+def _check_sink(sink, model_id) -> None:
+    if sink is not None and (not isinstance(sink, torch.Tensor) or sink.dim() != 1
+                             or sink.numel() != _hip.param_floats(model_id) or sink.dtype != torch.float32):
+        raise ValueError("gradient sink must be None or the flat fp32 gradient buffer of the whole model")
+
+
+def _param_grads(ctx, flat):
+    if ctx.sink_used:
+        return (None,) * ctx.nparams
+    grads, off = [], 0
+    for shp in ctx.shapes:
+        n = 1
+        for s in shp:
+            n *= s
+        grads.append(flat[off:off + n].view(shp))
         off += n
-    return out
+    return tuple(grads)
 
 
 class MLPFunction(torch.autograd.Function):
@@ -69,11 +92,13 @@ class MLPFunction(torch.autograd.Function):
     backward yields the 24 parameter gradients (flat buffer, state_dict order)."""
 
     @staticmethod
-    def forward(ctx, model_id, packed, points, dirs, train, *params):
+    def forward(ctx, model_id, packed, points, dirs, train, sink, *params):
         M = points.shape[0]
         colors, density, ws = _mlp_fwd(model_id, packed, M, train, points=points, dirs=dirs)
         ctx.model_id, ctx.M, ctx.train = model_id, M, train
         ctx.nparams = len(params)
+        _check_sink(sink, model_id)
+        ctx.sink, ctx.sink_used = sink, sink is not None
         if train:
             ctx.save_for_backward(packed, colors, ws)
             ctx.shapes = [p.shape for p in params]
@@ -88,15 +113,9 @@ class MLPFunction(torch.autograd.Function):
             dcolors = torch.zeros_like(colors)
         if ddensity is None:
             ddensity = torch.zeros((ctx.M,), dtype=torch.float32, device=colors.device)
-        flat = _hip.mlp_bwd(ctx.model_id, packed, ctx.M, _f32c(dcolors), _f32c(ddensity), colors, ws)
-        grads, off = [], 0
-        for shp in ctx.shapes:
-            n = 1
-            for s in shp:
-                n *= s
-            grads.append(flat[off:off + n].view(shp))
-            off += n
-        return (None, None, None, None, None, *grads)
+        flat = _hip.mlp_bwd(ctx.model_id, packed, ctx.M, _f32c(dcolors), _f32c(ddensity), colors, ws, ctx.sink,
+                            ctx.sink_used)
+        return (None,) * 6 + _param_grads(ctx, flat)
 
 
 class LinearActFunction(torch.autograd.Function):
@@ -133,7 +152,7 @@ class RenderFunction(torch.autograd.Function):
     inside the MLP kernel, colors/densities go straight to the compositing kernel."""
 
     @staticmethod
-    def forward(ctx, model_id, packed, rays_o, rays_d, t, deltas, near, far, white, want_extras, train, *params):
+    def forward(ctx, model_id, packed, rays_o, rays_d, t, deltas, near, far, white, want_extras, train, sink, *params):
         R, S = rays_o.shape[0], t.shape[-1]   # t is [S] (shared) or [R,S] (per ray)
         M = R * S
         colors, density, ws = _mlp_fwd(model_id, packed, M, train, rays_o=rays_o, rays_d=rays_d, t=t, S=S, near=near,
@@ -143,6 +162,9 @@ class RenderFunction(torch.autograd.Function):
         rgb, weights, depth, acc = _hip.composite_fwd(colors, density, deltas, white, t=t, want_weights=want_extras,
                                                       want_depth=want_extras, want_acc=want_extras)
         ctx.model_id, ctx.M, ctx.train, ctx.white = model_id, M, train, bool(white)
+        ctx.nparams = len(params)
+        _check_sink(sink, model_id)
+        ctx.sink, ctx.sink_used = sink, sink is not None
         if train:
             ctx.save_for_backward(packed, colors, density, deltas, ws)
             ctx.shapes = [p.shape for p in params]
@@ -157,15 +179,9 @@ class RenderFunction(torch.autograd.Function):
             raise RuntimeError("backward through an inference-mode forward")
         packed, colors, density, deltas, ws = ctx.saved_tensors
         dcolors, ddens = _hip.composite_bwd(colors, density, deltas, ctx.white, _f32c(grad_rgb))
-        flat = _hip.mlp_bwd(ctx.model_id, packed, ctx.M, dcolors.view(-1, 3), ddens.view(-1), colors.view(-1, 3), ws)
-        grads, off = [], 0
-        for shp in ctx.shapes:
-            n = 1
-            for s in shp:
-                n *= s
-            grads.append(flat[off:off + n].view(shp))
-            off += n
-        return (None,) * 11 + tuple(grads)
+        flat = _hip.mlp_bwd(ctx.model_id, packed, ctx.M, dcolors.view(-1, 3), ddens.view(-1), colors.view(-1, 3), ws,
+                            ctx.sink, ctx.sink_used)
+        return (None,) * 12 + _param_grads(ctx, flat)
 
 
 class CompositeFunction(torch.autograd.Function):

@@ -43,7 +43,10 @@ def shared_uniform(num_samples: int, device, generator: Optional[torch.Generator
 class FlatParameters:
     """Re-homes a module's parameters (and their .grad) as views of two flat fp32 buffers, in
     state_dict order.  One all-reduce and one optimizer launch then cover the whole model,
-    while state_dict()/load_state_dict()/torch.optim see the usual 24 tensors."""
+    while state_dict()/load_state_dict()/torch.optim see the usual 24 tensors.
+    For this package's fused modules the backward kernels add their result straight into the gradient
+    buffer (no per-tensor accumulation by autograd): drive training with loss.backward(), and zero
+    the gradients with zero_grad() of this class or of FusedAdam (never set_to_none)."""
 
     def __init__(self, module: torch.nn.Module):
         params = list(module.parameters())
@@ -62,6 +65,8 @@ class FlatParameters:
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
             off += n
+        if hasattr(module, "model_id"):
+            module._grad_sink = self.grad
 
     def zero_grad(self) -> None:
         """One memset; keeps .grad views attached (do not use set_to_none)."""

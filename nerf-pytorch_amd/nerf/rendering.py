@@ -13,7 +13,7 @@ import torch
 from torch import Tensor
 
 from . import _hip
-from .ops import CompositeFunction, RenderFunction, _f32c, wants_grad
+from .ops import CompositeFunction, RenderFunction, _f32c, grad_sink, wants_grad
 
 
 def stratified_sampling(near: float, far: float, num_bins: int, device: str = 'cpu', *,
@@ -108,6 +108,7 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
         params = model.ordered_parameters()
         train = wants_grad(params)
         packed = model.packed_weights(train)
+        sink = grad_sink(model, params) if train else None
     outs, extras = [], []
     for ci, i in enumerate(range(0, rays_o.shape[0], chunk_size)):
         o_chunk = rays_o[i:i + chunk_size]
@@ -115,7 +116,7 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
         t, deltas = _t_and_deltas(near, far, num_samples, rays_o.device, None if u is None else u[ci].to(rays_o.device))
         if fused:
             res = RenderFunction.apply(model.model_id, packed, o_chunk, d_chunk, t, deltas, float(near), float(far),
-                                       bool(white_background), bool(return_extras), train, *params)
+                                       bool(white_background), bool(return_extras), train, sink, *params)
             if return_extras:
                 outs.append(res[0])
                 extras.append(res[1:])
@@ -164,13 +165,15 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
     pc, pf = coarse.ordered_parameters(), fine.ordered_parameters()
     tc_train, tf_train = wants_grad(pc), wants_grad(pf)
     wc, wf = coarse.packed_weights(tc_train), fine.packed_weights(tf_train)
+    sink_c = grad_sink(coarse, pc) if tc_train else None
+    sink_f = grad_sink(fine, pf) if tf_train else None
     out_c, out_f, extras = [], [], []
     for ci, i in enumerate(range(0, rays_o.shape[0], chunk_size)):
         o, d = rays_o[i:i + chunk_size], rays_d[i:i + chunk_size]
         R = o.shape[0]
         t_c, deltas_c = _t_and_deltas(near, far, num_coarse, rays_o.device, None if u is None else u[ci].to(rays_o.device))
         rgb_c, w_c, _, _ = RenderFunction.apply(coarse.model_id, wc, o, d, t_c, deltas_c, float(near), float(far),
-                                                bool(white_background), True, tc_train, *pc)
+                                                bool(white_background), True, tc_train, sink_c, *pc)
         with torch.no_grad():
             t_mid = (0.5 * (t_c[1:] + t_c[:-1])).expand(R, -1).contiguous()          # [R, Nc-1] bin edges
             cdf = _hip.weights_to_cdf(w_c[:, 1:-1].contiguous())                      # [R, Nc-1]
@@ -178,7 +181,7 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
             t_f, _ = _hip.sample_pdf(t_mid, cdf, uf)
             t_all, deltas_all = _hip.merge_samples(t_c, t_f)
         res = RenderFunction.apply(fine.model_id, wf, o, d, t_all, deltas_all, float(near), float(far),
-                                   bool(white_background), bool(return_extras), tf_train, *pf)
+                                   bool(white_background), bool(return_extras), tf_train, sink_f, *pf)
         out_c.append(rgb_c)
         if return_extras:
             out_f.append(res[0])

@@ -30,7 +30,7 @@ def fwd():
 def dgrad():
     L.nerf_mlp_bwd_data(0, packed.data_ptr(), M, dc.data_ptr(), dd.data_ptr(), colors.data_ptr(), ws.data_ptr(), bw.data_ptr(), None)
 def wgrad():
-    L.nerf_mlp_bwd_weights(0, M, ws.data_ptr(), bw.data_ptr(), grads.data_ptr(), None)
+    L.nerf_mlp_bwd_weights(0, M, ws.data_ptr(), bw.data_ptr(), grads.data_ptr(), 0, None)
 def timed(seq, names, iters=8):
     tot = {n: 0.0 for n in names}
     for it in range(iters + 2):

@@ -374,6 +374,42 @@ def test_fused_adam_matches_torch_adam(hip):
     assert rel(p, pr) < 1e-6 and (p - pr.detach()).abs().max() < 1e-6
 
 
+def test_flat_bucket_receives_gradients_directly(hip):
+    """With parallel.FlatParameters the backward kernels add into the flat gradient bucket themselves
+    (accumulate flag of nerf_mlp_bwd_weights): same values as the per-tensor autograd path, accumulation
+    over chunks and over repeated backward calls, zero_grad() resets."""
+    from nerf import parallel
+    from nerf.rendering import render_nerf
+    model, _ = make_model("nerf")
+    o, d = rays(96, 71)
+    o, d = o.to(DEV), d.to(DEV)
+    us = [torch.rand(48, generator=torch.Generator().manual_seed(72 + i)).to(DEV) for i in range(3)]
+    tgt = torch.rand(96, 3, generator=torch.Generator().manual_seed(75)).to(DEV)
+
+    def loss():
+        return torch.nn.functional.mse_loss(
+            render_nerf(model, o, d, 2.0, 6.0, num_samples=48, device=DEV, chunk_size=40, u=us), tgt)
+
+    loss().backward()                                   # plain autograd path, three chunks accumulate
+    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    flat = parallel.FlatParameters(model)
+    assert model._grad_sink is flat.grad
+    flat.zero_grad()
+    loss().backward()
+    assert rel(flat.grad, ref) < 1e-6 and float(flat.grad.abs().max()) > 0
+    assert all(p.grad.data_ptr() >= flat.grad.data_ptr() for p in model.parameters())
+    loss().backward()                                   # a second backward adds
+    assert rel(flat.grad, 2 * ref) < 1e-6
+    flat.zero_grad()
+    assert float(flat.grad.abs().max()) == 0.0
+    # detached .grad (e.g. set_to_none): the sink is not used, autograd gets per-tensor gradients again
+    for p in model.parameters():
+        p.grad = None
+    loss().backward()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert rel(got, ref) < 1e-6 and float(flat.grad.abs().max()) == 0.0
+
+
 # ----------------------------------------------------------------------------- full-size properties
 @pytest.mark.parametrize("tag", ["nerf", "siren"])
 def test_full_size_properties(hip, tag):
@@ -685,7 +721,7 @@ def test_hierarchical_render_vs_oracle(tag):
     t_all = t_all.contiguous()
     d_all = torch.cat([t_all[:, 1:] - t_all[:, :-1], torch.full((R, 1), 1e10)], dim=1)
     rgb_f2 = RenderFunction.apply(fine.model_id, fine.packed_weights(), o.to(DEV), d.to(DEV), t_all.to(DEV),
-                                  d_all.to(DEV), 2.0, 6.0, True, False, True, *fine.ordered_parameters())
+                                  d_all.to(DEV), 2.0, 6.0, True, False, True, None, *fine.ordered_parameters())
     assert rel(rgb_f2, rf) < RTOL
     torch.nn.functional.mse_loss(rgb_f2, tgt.to(DEV)).backward()
     gf_ref = torch.autograd.grad(torch.nn.functional.mse_loss(rf, tgt), list(pf.values()))
