@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16: the opt-in inference mode (--mode infer, nerf only); never the default metric")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --one-device rehearses the multi-rank code path on a box with a single GPU")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     args = ap.parse_args()
@@ -148,8 +151,13 @@ def main():
     if args.gpus > 1 or world > 1:
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        if args.one_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -160,6 +168,13 @@ def main():
 
     torch.manual_seed(42)
     np.random.seed(42)
+    verbose = bool(os.environ.get("BENCH_VERBOSE"))
+
+    def note(msg):
+        if verbose:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    note("process group up")
     hier = args.sampling == "hier"
     Model = NeRF if args.model == "nerf" else Siren
     models = [Model().to(dev) for _ in range(2 if hier else 1)]   # [coarse, fine] or [single]
@@ -183,7 +198,14 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     ugen = torch.Generator(device=dev).manual_seed(999)  # same seed on all ranks; also broadcast
 
+    def host_sync_for_gloo():
+        # rehearsal backend only: gloo stages device tensors through the host and, with several ranks
+        # on ONE device, was seen to stall unless the device is idle when the collective starts
+        if world > 1 and args.dist_backend == "gloo":
+            torch.cuda.synchronize()
+
     def render(o, d):
+        host_sync_for_gloo()
         if hier:
             u = parallel.shared_uniform(args.coarse, dev, ugen)
             rc, rf = render_nerf_hierarchical(models[0], models[1], o, d, near, far, args.coarse, args.fine, device=dev,
@@ -202,6 +224,7 @@ def main():
         loss = sum(torch.nn.functional.mse_loss(p, tgt) for p in preds)
         loss.backward()
         for f, opt in zip(flats, opts):
+            host_sync_for_gloo()
             f.all_reduce_mean()
             opt.lr = opt.base_lr * parallel.lr_lambda(step, opt.base_lr, 300.0, 0.1, 1e-4)
             opt.step()
@@ -219,9 +242,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note("rays ready")
     for i in range(args.warmup):
         step_fn(i)
+        note(f"warmup step {i} done")
     barrier()
+    note("timed region starts")
     _hip.timers.enabled = True
     _hip.timers.reset()
     t0 = time.perf_counter()
