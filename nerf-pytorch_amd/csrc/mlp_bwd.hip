@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void nerf_dgrad_kernel(BwdArgs a) {
     dgrad_layer<3, true>(act, pk + d_img(9), H / 8, ncol0, tid, nullptr, bw + BW_DZ9 * Mp + m0 * H, H, dsig_s, pk + SIGW,
                          mskp(8));
     // layers 8..1: dz_l -> dz_(l-1) (layer 5 only through its feature columns)
+#pragma unroll 1   // one copy of the layer body (instruction cache)
     for (int l = 8; l >= 1; --l)
         dgrad_layer<3, false>(act, pk + d_img(l), H / 8, ncol0, tid, nullptr, dzp(l), H, nullptr, nullptr, mskp(l - 1));
     store_tile(act, H, dzp(0), H, tid);
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void siren_dgrad_kernel(BwdArgs a) {
     // feature_remap + density branch (rank-1) -> dh7, times cos -> dz7
     dgrad_layer<2, true>(act, pk + D_FEAT, H / 8, ncol0, tid, ws + (WS_C + 7 * (size_t)H) * Mp + m0 * H,
                          bw + BW_DZF * Mp + m0 * H, H, dsig_s, pk + SIGW);
+#pragma unroll 1   // one copy of the layer body (instruction cache)
     for (int l = 7; l >= 1; --l)
         dgrad_layer<2, false>(act, pk + d_img(l), H / 8, ncol0, tid, ws + (WS_C + (size_t)(l - 1) * H) * Mp + m0 * H,
                               dzp(l), H, nullptr, nullptr);

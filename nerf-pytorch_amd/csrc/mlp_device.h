@@ -135,7 +135,7 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                 }
                 if constexpr (ACT == ACT_SIN) {
                     float s;
-                    nerf_sincosf(v, &s, &c);
+                    nerf_sincosf_bounded(v, &s, &c);   // layer input is a sine layer's output: |v| <= sum|w| + |b|
                     v = s;
                 }
                 act[row * LDA + col] = v;
@@ -188,12 +188,14 @@ __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
 template <int L>
 __device__ __forceinline__ void encode_axis(float* dst, int axis, float x) {
     dst[axis] = x;
-#pragma unroll
+    float scale = 1.0f;
+#pragma unroll 1   // one copy of the full-range sincos (its large-argument path is ~100 instructions)
     for (int j = 0; j < L; ++j) {
         float s, c;
-        nerf_sincosf(mul_rn((float)(1 << j), x), &s, &c);
+        nerf_sincosf(mul_rn(scale, x), &s, &c);
         dst[3 + 6 * j + axis] = s;
         dst[3 + 6 * j + 3 + axis] = c;
+        scale *= 2.0f;
     }
 }
 

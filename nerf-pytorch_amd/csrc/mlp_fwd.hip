@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
     hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L0, PE_P / 8, pk + BIAS, ncol0, tid, wsp(WS_PE, PE_P), PE_P, nullptr, nullptr,
                                   &mask);
     // L1..L4 (input tile = h(l-1))
+#pragma unroll 1   // one copy of the layer body: unrolled, the kernel outgrows the instruction cache
     for (int l = 1; l <= 4; ++l) {
         hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
                                       tid, wsp(WS_H + (size_t)(l - 1) * H, H), H, nullptr, mskp(l - 1), &mask);
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         __syncthreads();
     }
     // L6..L8
+#pragma unroll 1   // one copy of the layer body: unrolled, the kernel outgrows the instruction cache
     for (int l = 6; l <= 8; ++l)
         hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L6 + (size_t)(l - 6) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
                                       tid, wsp(WS_H + (size_t)(l - 1) * H, H), H, nullptr, mskp(l - 1), &mask);
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
     }
     __syncthreads();
     const int ncol0 = wave * 64;
+#pragma unroll 1   // one copy of the layer body: unrolled, the kernel outgrows the instruction cache
     for (int l = 1; l <= 7; ++l)
         hidden_layer<ACT_SIN, TRAIN>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), H / 8, pk + BIAS + l * H, ncol0, tid,
                                      wsp(WS_H + (size_t)(l - 1) * H, H), H, wsp(WS_C + (size_t)l * H, H));

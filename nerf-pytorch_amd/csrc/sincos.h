@@ -11,11 +11,11 @@
 #define NERF_HD inline
 #endif
 
-NERF_HD void nerf_sincosf(float x, float* sn, float* cs) {
-    if (!(fabsf(x) <= 1.0e5f)) {  // also catches NaN
-        sincosf(x, sn, cs);
-        return;
-    }
+// The reduction + polynomials alone.  For |x| <= 1e5 this IS nerf_sincosf; beyond that the error grows
+// smoothly (kf*P1 stops being exact) instead of switching to the library's Payne-Hanek path, whose
+// inlined code is ~100 instructions per call site.  For call sites whose argument is bounded by
+// construction: pre-activations of sine layers fed by sines (|z| <= sum|w| + |b|).
+NERF_HD void nerf_sincosf_bounded(float x, float* sn, float* cs) {
     const float kf = rintf(x * 0.63661977236758134f);  // nearest multiple of pi/2
     // pi/2 = P1 + P2 + P3; P1 has 8 significant bits, so kf*P1 is exact for |kf| < 2^16
     float r = fmaf(-kf, 1.5703125f, x);
@@ -34,4 +34,12 @@ NERF_HD void nerf_sincosf(float x, float* sn, float* cs) {
     const float c0 = (q & 1) ? ps : pc;
     *sn = (q & 2) ? -s0 : s0;
     *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+NERF_HD void nerf_sincosf(float x, float* sn, float* cs) {
+    if (!(fabsf(x) <= 1.0e5f)) {  // also catches NaN
+        sincosf(x, sn, cs);
+        return;
+    }
+    nerf_sincosf_bounded(x, sn, cs);
 }
