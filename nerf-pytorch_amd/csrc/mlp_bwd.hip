@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
     constexpr int TN = NW / WN / 32, TK = KW / WK / 32;
     constexpr int ROWF = NW + KW;             // floats per staged sample row
     constexpr int BUF = 32 * ROWF + 32;       // floats per buffer: dY, X, then 32 values of q
-    static_assert(TN >= 1 && TK >= 1 && WN * WK <= 8, "wave layout");
+    static_assert(TN >= 1 && TK >= 1 && WN * WK <= 8 && TN != 3 && TK != 3, "wave layout");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,16 +236,29 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
         float* nbuf = smem + (((c - c0) & 1) ^ 1) * BUF;
         if (c + 1 < c1) stage(c + 1, nbuf);  // nbuf was last read before the previous barrier
         if (active) {
-            const float* ap = buf + wn * (NW / WN) + r + h * NW;
-            const float* bp = buf + 32 * NW + wk * (KW / WK) + r + h * KW;
+            // Tile i of this wave covers output rows n0 + TN*rho + i (rho = the MFMA row index) and tile j
+            // columns k0 + TK*col + j: a lane's TN A values and TK B values of a sample are then adjacent
+            // floats -- one vector read each instead of TN + TK scalar reads per sample pair.
+            const float* ap = buf + wn * (NW / WN) + TN * r + h * NW;
+            const float* bp = buf + 32 * NW + wk * (KW / WK) + TK * r + h * KW;
             // fragments of sample pair s+1 are read from LDS before the MFMAs of pair s (two named
             // register sets, pinned): otherwise every 4-8 MFMAs wait for an LDS round trip
             float av0[TN], bv0[TK], av1[TN], bv1[TK];
             auto lds_frags = [&](int s, float (&av)[TN], float (&bv)[TK]) {
+                typedef float vecn __attribute__((ext_vector_type(TN == 3 ? 4 : TN)));
+                typedef float veck __attribute__((ext_vector_type(TK == 3 ? 4 : TK)));
+                if constexpr (TN == 1) av[0] = ap[2 * s * NW];
+                else {
+                    const vecn v = *reinterpret_cast<const vecn*>(ap + 2 * s * NW);
 #pragma unroll
-                for (int i = 0; i < TN; ++i) av[i] = ap[2 * s * NW + 32 * i];
+                    for (int i = 0; i < TN; ++i) av[i] = v[i];
+                }
+                if constexpr (TK == 1) bv[0] = bp[2 * s * KW];
+                else {
+                    const veck v = *reinterpret_cast<const veck*>(bp + 2 * s * KW);
 #pragma unroll
-                for (int j = 0; j < TK; ++j) bv[j] = bp[2 * s * KW + 32 * j];
+                    for (int j = 0; j < TK; ++j) bv[j] = v[j];
+                }
             };
             auto mma = [&](float (&av)[TN], float (&bv)[TK]) {
 #pragma unroll
@@ -283,16 +296,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
     }
     if (active) {
         float* out = a.slab + (size_t)bid * NW * KW;
+        const int n0 = wn * (NW / WN), k0 = wk * (KW / WK);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int j = 0; j < TK; ++j) {
-                const int n0 = wn * (NW / WN) + 32 * i, k0 = wk * (KW / WK) + 32 * j;
+            for (int g = 0; g < 16; ++g) {
+                const int rho = (g & 3) + 8 * (g >> 2) + 4 * h;
+                float* dst = out + (size_t)(n0 + TN * rho + i) * KW + k0 + TK * r;   // TK adjacent columns
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
-                    out[(size_t)(n0 + row) * KW + k0 + r] = acc[i][j][g];
-                }
+                for (int j = 0; j < TK; ++j) dst[j] = acc[i][j][g];
             }
     }
     // the last barrier of the loop has passed: the staging buffers are free for the cross-group sums
