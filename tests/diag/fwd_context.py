@@ -24,7 +24,13 @@ bw = torch.empty(_hip.lib.nerf_mlp_bwd_workspace_floats(0, M), device="cuda")
 grads = torch.empty(_hip.param_floats(0), device="cuda")
 dc = torch.randn(M, 3, device="cuda") * 1e-3; dd = torch.randn(M, device="cuda") * 1e-3
 L = _hip.lib
+REALLOC = "realloc" in sys.argv   # a fresh workspace per call, as the autograd path allocates it
 def fwd():
+    global ws, bw
+    if REALLOC:
+        ws = None; bw = None
+        ws = torch.empty(_hip.lib.nerf_mlp_fwd_workspace_floats(0, M), device="cuda")
+        bw = torch.empty(_hip.lib.nerf_mlp_bwd_workspace_floats(0, M), device="cuda")
     L.nerf_mlp_fwd(0, packed.data_ptr(), M, None, None, o.data_ptr(), d.data_ptr(), t.data_ptr(), S, 0, 2.0, 6.0,
                    colors.data_ptr(), dens.data_ptr(), ws.data_ptr(), None)
 def dgrad():
