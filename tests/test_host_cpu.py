@@ -58,6 +58,22 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.nerf_sample_positions(None, None, None, 0, 64, 0, 2.0, 6.0, None, None) == 0
 
 
+def test_argument_errors_of_the_optional_paths():
+    """bf16 mode and layer-wise path: sizes and argument checks that need no GPU."""
+    from nerf import _hip
+    lib = _hip.lib
+    assert lib.nerf_mlp_packed_bf16_bytes(_hip.MODEL_NERF) == 43 * 32768 + 86 * 32 * 4
+    assert lib.nerf_mlp_packed_bf16_bytes(_hip.MODEL_SIREN) == 0
+    assert lib.nerf_mlp_fwd_bf16(_hip.MODEL_SIREN, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -1
+    assert b"NeRF model only" in lib.nerf_last_error()
+    assert lib.nerf_mlp_fwd_bf16(_hip.MODEL_NERF, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -2
+    assert lib.nerf_linear_fwd(None, 4, None, None, 10, 8, 3, 0, 1.0, 1.0, None, 3, None, None) == -1   # ldx < K
+    assert lib.nerf_linear_fwd(None, 8, None, None, 10, 8, 3, 9, 1.0, 1.0, None, 3, None, None) == -1   # activation
+    assert lib.nerf_linear_fwd(None, 8, None, None, 0, 8, 3, 0, 1.0, 1.0, None, 3, None, None) == 0     # empty batch
+    assert lib.nerf_linear_bwd_workspace_floats(100, 8, 3) == 100 * 3 + 1 * (3 * 8 + 3)
+    assert lib.nerf_linear_bwd_workspace_floats(-1, 8, 3) == 0
+
+
 def test_no_cpu_fallback():
     from nerf.models import NeRF
     from nerf.rendering import render_nerf, composite_volume
