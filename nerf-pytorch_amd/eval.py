@@ -2,7 +2,9 @@
 
 Poses as reference eval.py:14-41,91-97 (theta sweep, phi = -30 deg, radius 4), rays generated
 on the device, frames quantised as (clip(rgb,0,1)*255) truncated to uint8 (eval.py:149-150) and
-written as PNG.  With torchrun the poses are sharded over ranks (no collective)."""
+written as PNG.  With torchrun the poses are sharded over ranks (no collective).  A checkpoint of a
+coarse + fine pair (train.py with `num_fine_samples`) is rendered hierarchically; `--precision bf16`
+selects the opt-in bf16 inference kernels (NeRF only)."""
 import argparse
 import os
 import sys
@@ -14,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from nerf.data import compute_rays_device, load_dataset  # noqa: E402
 from nerf.models import NeRF, Siren  # noqa: E402
-from nerf.rendering import render_nerf  # noqa: E402
+from nerf.rendering import render_nerf, render_nerf_hierarchical  # noqa: E402
 from nerf.utils import parse_config  # noqa: E402
 
 
@@ -56,6 +58,7 @@ def main(argv=None):
     ap.add_argument('--checkpoint', type=str, required=True)
     ap.add_argument('--output', type=str, default='rendered_frames')
     ap.add_argument('--resolution', type=int, default=None, help='override H=W (default: the test image size)')
+    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32')
     args = ap.parse_args(argv)
     cfg = parse_config(args.config)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,14 +75,29 @@ def main(argv=None):
     chunk_size = int(cfg.get('chunk_size', 8192))
     n_poses = int(cfg.get('num_render_poses', 40))
     os.makedirs(args.output, exist_ok=True)
-    if model_type == 'nerf':
-        model = NeRF().to(device)
-    elif model_type == 'siren':
-        model = Siren().to(device)
-    else:
+    if model_type not in ('nerf', 'siren'):
         raise ValueError(f"Invalid model type: {model_type}")
-    model.load_state_dict(ckpt['model_state_dict'])
+    make = NeRF if model_type == 'nerf' else Siren
+    state = ckpt['model_state_dict']
+    pair = any(k.startswith('coarse.') for k in state)
+    if pair:
+        model = torch.nn.ModuleDict({"coarse": make(), "fine": make()}).to(device)
+        nets = [model["coarse"], model["fine"]]
+        num_fine = int(cfg.get('num_fine_samples', 128))
+    else:
+        model = make().to(device)
+        nets = [model]
+    model.load_state_dict(state)
     model.eval()
+    for n in nets:
+        n.set_inference_precision(args.precision)
+
+    def render(o, d):
+        if pair:
+            return render_nerf_hierarchical(nets[0], nets[1], o, d, near, far, num_samples, num_fine, device=device,
+                                            white_background=True, chunk_size=chunk_size)[1]
+        return render_nerf(nets[0], o, d, near, far, num_samples=num_samples, device=device, white_background=True,
+                           chunk_size=chunk_size)
 
     images, _, focal = load_dataset(cfg.get('dataset_path', './datasets/lego'), mode='test', single_image=True)
     H, W = images.shape[1:3]
@@ -91,8 +109,7 @@ def main(argv=None):
         c2w = torch.from_numpy(pose_spherical(float(angles[i]), -30.0, 4.0))[None].to(device)
         ro, rd = compute_rays_device(H, W, c2w, focal)
         with torch.no_grad():
-            rgb = render_nerf(model, ro[0], rd[0], near, far, num_samples=num_samples, device=device,
-                              white_background=True, chunk_size=chunk_size)
+            rgb = render(ro[0], rd[0])
         frame = quantise(rgb.reshape(H, W, 3)).cpu().numpy()
         write_png(os.path.join(args.output, f"frame_{i:04d}.png"), frame)
     if rank == 0:

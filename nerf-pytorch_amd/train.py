@@ -5,6 +5,9 @@ Same config keys, seeding, Adam + LambdaLR schedule, logging / checkpoint / vali
 optimizer is one fused Adam launch over a flat parameter buffer (`--optimizer torch` selects
 torch.optim.Adam + LambdaLR exactly as the reference), TensorBoard is optional, and
 `torchrun --nproc-per-node N train.py ...` shards every batch's rays over N GPUs.
+Extension (no counterpart in the reference): the config key `num_fine_samples = N` (N > 0) trains a
+coarse and a fine network with inverse-CDF re-sampling (`num_samples` coarse + N fine samples per
+ray, both losses); checkpoints then hold both networks under `coarse.` / `fine.` key prefixes.
 """
 import argparse
 import datetime
@@ -21,7 +24,7 @@ from nerf import parallel  # noqa: E402
 from nerf.data import DeviceRays, compute_rays_device, load_dataset  # noqa: E402
 from nerf.loss import mse_to_psnr  # noqa: E402
 from nerf.models import NeRF, Siren  # noqa: E402
-from nerf.rendering import render_nerf  # noqa: E402
+from nerf.rendering import render_nerf, render_nerf_hierarchical  # noqa: E402
 from nerf.utils import format_elapsed_time, log_training_metrics, parse_config, save_checkpoint  # noqa: E402
 
 
@@ -31,6 +34,37 @@ def build_model(model_type: str):
     if model_type == 'siren':
         return Siren()
     raise ValueError(f"Invalid model type: {model_type}")
+
+
+class OptimizerGroup:
+    """Several FusedAdam instances (one per network) behind the interface the loop uses."""
+
+    def __init__(self, opts):
+        self.opts = list(opts)
+
+    @property
+    def lr(self):
+        return self.opts[0].lr
+
+    @lr.setter
+    def lr(self, value):
+        for o in self.opts:
+            o.lr = value
+
+    def zero_grad(self):
+        for o in self.opts:
+            o.zero_grad()
+
+    def step(self):
+        for o in self.opts:
+            o.step()
+
+    def state_dict(self):
+        return {"group": [o.state_dict() for o in self.opts]}
+
+    def load_state_dict(self, sd):
+        for o, s in zip(self.opts, sd["group"]):
+            o.load_state_dict(s)
 
 
 def main(argv=None):
@@ -70,6 +104,9 @@ def main(argv=None):
     first_step_render = cfg.get('first_step_render', 'False').lower() == 'true'
     log_interval = int(cfg.get('log_interval', 10))
     val_interval = int(cfg.get('val_interval', 1000))
+    num_fine = int(cfg.get('num_fine_samples', 0))
+    if num_fine > 0 and args.optimizer != 'fused':
+        raise ValueError("num_fine_samples > 0 (coarse + fine networks) needs --optimizer fused")
     if args.max_iters is not None:
         num_iters = min(num_iters, args.max_iters)
     os.makedirs(save_path, exist_ok=True)
@@ -84,7 +121,21 @@ def main(argv=None):
         print(f"===== Training: {model_type}, {num_random_rays} rays x {num_samples} samples, {num_iters} iters, "
               f"lr {learning_rate}, world {world}, device {torch.cuda.get_device_name(device)} =====")
 
-    model = build_model(model_type).to(device)
+    if num_fine > 0:
+        model = torch.nn.ModuleDict({"coarse": build_model(model_type), "fine": build_model(model_type)}).to(device)
+        nets = [model["coarse"], model["fine"]]
+    else:
+        model = build_model(model_type).to(device)
+        nets = [model]
+
+    def render(o, d, us=None, ufs=None):
+        """rgb predictions of every network that is trained ([single] or [coarse, fine])."""
+        if num_fine > 0:
+            return list(render_nerf_hierarchical(nets[0], nets[1], o, d, near, far, num_samples, num_fine, device=device,
+                                                 white_background=True, chunk_size=chunk_size, u=us, u_fine=ufs))
+        return [render_nerf(nets[0], o, d, near, far, num_samples=num_samples, device=device, white_background=True,
+                            chunk_size=chunk_size, u=us)]
+
     images, c2w, focal = load_dataset(dataset_path, mode='train')
     images_val, c2w_val, focal_val = load_dataset(dataset_path, mode='val')
     N_val = images.shape[0]  # the reference indexes validation images with the TRAIN count (train.py:115)
@@ -99,9 +150,12 @@ def main(argv=None):
         sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: max(gamma ** s, lr_min / learning_rate))
         flat = None
     else:
-        flat = parallel.FlatParameters(model)
-        flat.broadcast_parameters(0)
-        opt = parallel.FusedAdam(flat, lr=learning_rate)
+        flats = [parallel.FlatParameters(n) for n in nets]
+        for f in flats:
+            f.broadcast_parameters(0)
+        fused = [parallel.FusedAdam(f, lr=learning_rate) for f in flats]
+        opt = fused[0] if len(fused) == 1 else OptimizerGroup(fused)
+        flat = flats
     start_iter = 0
     if ckpt is not None:
         try:
@@ -132,13 +186,14 @@ def main(argv=None):
             o, d, tgt = o[per_rank], d[per_rank], tgt[per_rank]
             n_chunks = (o.shape[0] + chunk_size - 1) // chunk_size
             us = [parallel.shared_uniform(num_samples, device) for _ in range(n_chunks)]
-            pred = render_nerf(model, o, d, near, far, num_samples=num_samples, device=device, white_background=True,
-                               chunk_size=chunk_size, u=us)
+            preds = render(o, d, us)
             opt.zero_grad()
-            loss = mse(pred, tgt)
+            loss = sum(mse(p, tgt) for p in preds)
             loss.backward()
+            loss = mse(preds[-1].detach(), tgt)   # what is logged: the loss of the image that is kept
             if flat is not None:
-                flat.all_reduce_mean()
+                for f in flat:
+                    f.all_reduce_mean()
                 opt.lr = learning_rate * parallel.lr_lambda(step, learning_rate, lr_decay, lr_decay_factor, lr_min)
             opt.step()
             if sched is not None:
@@ -157,8 +212,7 @@ def main(argv=None):
                 ro, rd = compute_rays_device(H, W, torch.from_numpy(c2w_val[i:i + 1]).to(device), focal_val)
                 model.eval()
                 with torch.no_grad():
-                    img = render_nerf(model, ro[0], rd[0], near, far, num_samples=num_samples, device=device,
-                                      white_background=True, chunk_size=chunk_size)
+                    img = render(ro[0], rd[0])[-1]
                 model.train()
                 img = img.reshape(H, W, 3).cpu().numpy()
                 val_mse = float(np.mean((img - images_val[i]) ** 2))

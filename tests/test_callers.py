@@ -32,9 +32,10 @@ def make_dataset(root, n=3, res=12):
     return root
 
 
-def write_config(path, dataset, save_path, model_type="nerf"):
+def write_config(path, dataset, save_path, model_type="nerf", extra=""):
     with open(path, "w") as f:
         f.write(f"""# test config
+{extra}
 dataset_path = {dataset}   # where
 num_random_rays = 96
 chunk_size = 64
@@ -159,8 +160,12 @@ def test_device_rays_epoch_semantics(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model_type,optimizer", [("nerf", "fused"), ("siren", "torch")])
-def test_train_resume_eval_end_to_end(tmp_path, capsys, model_type, optimizer):
+@pytest.mark.parametrize("model_type,optimizer,extra,eval_args", [
+    ("nerf", "fused", "", []),
+    ("siren", "torch", "", []),
+    ("nerf", "fused", "num_fine_samples = 16", ["--precision", "bf16"]),   # coarse + fine pair, bf16 inference
+])
+def test_train_resume_eval_end_to_end(tmp_path, capsys, model_type, optimizer, extra, eval_args):
     sys.path.insert(0, PKG)
     import importlib
     train = importlib.import_module("train")
@@ -168,7 +173,7 @@ def test_train_resume_eval_end_to_end(tmp_path, capsys, model_type, optimizer):
     root = make_dataset(str(tmp_path / "ds"))
     save = str(tmp_path / "models")
     cfgp = str(tmp_path / "cfg.txt")
-    write_config(cfgp, root, save, model_type)
+    write_config(cfgp, root, save, model_type, extra)
     cwd = os.getcwd()
     os.chdir(str(tmp_path))
     try:
@@ -180,7 +185,11 @@ def test_train_resume_eval_end_to_end(tmp_path, capsys, model_type, optimizer):
         train.main(["--config", cfgp, "--optimizer", optimizer, "--resume", os.path.join(save, files[1])])
         out = capsys.readouterr().out
         assert "[Iter 0000004]" in out and "[Iter 0000003]" not in out
-        ev.main(["--config", cfgp, "--checkpoint", os.path.join(save, files[2]), "--output", str(tmp_path / "frames")])
+        ev.main(["--config", cfgp, "--checkpoint", os.path.join(save, files[2]), "--output", str(tmp_path / "frames")]
+                + eval_args)
+        if extra:
+            sd = torch.load(os.path.join(save, files[2]), map_location="cpu", weights_only=True)["model_state_dict"]
+            assert any(k.startswith("coarse.") for k in sd) and any(k.startswith("fine.") for k in sd)
         from PIL import Image
         fr = np.asarray(Image.open(str(tmp_path / "frames" / "frame_0001.png")))
         assert fr.shape == (12, 12, 3) and fr.dtype == np.uint8
