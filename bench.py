@@ -7,7 +7,7 @@
 A step = one pass of the hot path over one batch of synthetic rays already resident in HBM:
 draw u, stratified t, fused sample+encode+MLP forward, compositing, MSE, compositing backward,
 fused MLP data-gradient chain, per-layer weight gradients, (N>1: one RCCL all-reduce of the flat
-gradient bucket), one fused Adam launch, weight re-pack.  Workload = BASELINE.json configs[1]:
+gradient bucket), one fused Adam launch, weight re-pack.  Workload (the single-GPU training configuration the headline rate is quoted on):
 lego-shaped synthetic 800x800 scene, 4096 rays per GPU per step, 256 MLP evaluations per ray
 (the reference's num_samples = 256 single pass, config_lego.txt:15; same FLOPs as 64 coarse +
 64+128 fine), NeRF model, fp32.  Weak scaling: every rank renders its own 4096-ray slice of a

@@ -413,7 +413,7 @@ def test_flat_bucket_receives_gradients_directly(hip):
 # ----------------------------------------------------------------------------- full-size properties
 @pytest.mark.parametrize("tag", ["nerf", "siren"])
 def test_full_size_properties(hip, tag):
-    """BASELINE configuration 2 size (4096 rays x 256 samples = 1,048,576 MLP evaluations), where
+    """Training batch size (4096 rays x 256 samples = 1,048,576 MLP evaluations), where
     the CPU oracle would take minutes: size-independent properties instead.
       * fused ray path == explicit points path + compositing kernel (bitwise in colors);
       * gradients are linear in the upstream gradient: scaling by 2 is exact in fp32, so the
@@ -456,7 +456,7 @@ def test_full_size_properties(hip, tag):
 
 
 def test_large_batch_inference_properties(hip):
-    """BASELINE configuration 5 size in fp32: 262,144 rays x 256 samples = 67,108,864 MLP
+    """Largest inference batch in fp32: 262,144 rays x 256 samples = 67,108,864 MLP
     evaluations, rendered without gradients in chunks of 8192 rays (nothing but the [R,3] result
     scales with R in HBM).  Size-independent properties:
       * chunking is invisible: any ray rendered alone with the same draw is bit-identical;
@@ -587,7 +587,7 @@ def test_bf16_inference_vs_restatement(hip, M):
 
 
 def test_bf16_render_tolerance_report(hip):
-    """BASELINE configuration 5 shape (rays x 256 samples, bf16 opt-in): rendered RGB of the bf16 mode
+    """Large-batch inference shape (rays x 256 samples, bf16 opt-in): rendered RGB of the bf16 mode
     against the fp32 mode on the same rays and draws.  Stated tolerance of the mode: PSNR between the
     two renders above 40 dB, mean absolute deviation below 5e-3, 99.9 % of the channel values within
     3e-2 (compositing amplifies a density deviation on the few rays that graze a surface, so the
