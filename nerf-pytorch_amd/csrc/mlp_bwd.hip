@@ -71,11 +71,11 @@ __device__ __forceinline__ void head_bwd(const BwdArgs& a, size_t m0, float* act
 }
 
 // one data-gradient step on the tile: dX = dY * W (transposed image), epilogue, barriers.
-// gin (may be NULL): where the layer's INPUT tile (dY, in_cols columns) goes in the backward
-// workspace; it is copied out after the MFMA loop that consumed it, while still intact in LDS.
-template <int MASK, bool RANK1>
+// COPY_COLS != 0 (= 8*kb_count): the layer's INPUT tile (dY) goes to gin in the backward workspace,
+// copied by the MFMA loop that consumes it.
+template <int MASK, bool RANK1, int COPY_COLS>
 __device__ __forceinline__ void dgrad_layer(float* act, const float* __restrict__ timg, int kb_count, int ncol0,
-                                            int tid, const float* hsrc, float* gin, int in_cols, const float* dsig_s,
+                                            int tid, const float* hsrc, float* gin, const float* dsig_s,
                                             const float* __restrict__ sigw,
                                             const unsigned long long* __restrict__ mask_word = nullptr) {
     const int lane = tid & 63;
@@ -83,8 +83,7 @@ __device__ __forceinline__ void dgrad_layer(float* act, const float* __restrict_
     init_bias<2>(acc, nullptr, ncol0, lane);
     unsigned long long bits = 0ull;
     if constexpr (MASK == 3) bits = *mask_word;  // one 8-byte load, in flight during the whole K loop
-    mma_layer<2>(act, timg, lay::H, kb_count, ncol0, lane, acc);
-    if (gin) store_tile(act, in_cols, gin, in_cols, tid);
+    mma_layer<2, COPY_COLS>(act, timg, lay::H, kb_count, ncol0, lane, acc, gin, tid);
     __syncthreads();
     bwd_epilogue<2, MASK, RANK1>(act, acc, ncol0, lane, hsrc, lay::H, dsig_s, sigw, bits);
     __syncthreads();
@@ -110,17 +109,17 @@ __global__ __launch_bounds__(256, 2) void nerf_dgrad_kernel(BwdArgs a) {
                     bw + BW_DSIG * Mp, bw + BW_DZ10 * Mp, tid);
     __syncthreads();
     // rgb_head.0 (feature part): reduce over its 128 outputs -> gradient of the 256 features (dz9)
-    dgrad_layer<0, false>(act, pk + D10, HH / 8, ncol0, tid, nullptr, nullptr, 0, nullptr, nullptr);
+    dgrad_layer<0, false, 0>(act, pk + D10, HH / 8, ncol0, tid, nullptr, nullptr, nullptr, nullptr);
     auto mskp = [&](int l) {
         return reinterpret_cast<const unsigned long long*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid;
     };
     // block2.8: 256 feature rows on MFMA + the density row as a rank-1 term, ReLU mask of h8 -> dz8
-    dgrad_layer<3, true>(act, pk + d_img(9), H / 8, ncol0, tid, nullptr, bw + BW_DZ9 * Mp + m0 * H, H, dsig_s, pk + SIGW,
-                         mskp(8));
+    dgrad_layer<3, true, H>(act, pk + d_img(9), H / 8, ncol0, tid, nullptr, bw + BW_DZ9 * Mp + m0 * H, dsig_s, pk + SIGW,
+                            mskp(8));
     // layers 8..1: dz_l -> dz_(l-1) (layer 5 only through its feature columns)
 #pragma unroll 1   // one copy of the layer body (instruction cache)
     for (int l = 8; l >= 1; --l)
-        dgrad_layer<3, false>(act, pk + d_img(l), H / 8, ncol0, tid, nullptr, dzp(l), H, nullptr, nullptr, mskp(l - 1));
+        dgrad_layer<3, false, H>(act, pk + d_img(l), H / 8, ncol0, tid, nullptr, dzp(l), nullptr, nullptr, mskp(l - 1));
     store_tile(act, H, dzp(0), H, tid);
 }
 
@@ -144,14 +143,14 @@ __global__ __launch_bounds__(256, 2) void siren_dgrad_kernel(BwdArgs a) {
                    bw + BW_DSIG * Mp, bw + BW_DZR * Mp, tid);
     __syncthreads();
     // rgb sine layer (feature part) -> gradient of feature_remap's output (dzf)
-    dgrad_layer<0, false>(act, pk + D_RGB, HH / 8, ncol0, tid, nullptr, nullptr, 0, nullptr, nullptr);
+    dgrad_layer<0, false, 0>(act, pk + D_RGB, HH / 8, ncol0, tid, nullptr, nullptr, nullptr, nullptr);
     // feature_remap + density branch (rank-1) -> dh7, times cos -> dz7
-    dgrad_layer<2, true>(act, pk + D_FEAT, H / 8, ncol0, tid, ws + (WS_C + 7 * (size_t)H) * Mp + m0 * H,
-                         bw + BW_DZF * Mp + m0 * H, H, dsig_s, pk + SIGW);
+    dgrad_layer<2, true, H>(act, pk + D_FEAT, H / 8, ncol0, tid, ws + (WS_C + 7 * (size_t)H) * Mp + m0 * H,
+                            bw + BW_DZF * Mp + m0 * H, dsig_s, pk + SIGW);
 #pragma unroll 1   // one copy of the layer body (instruction cache)
     for (int l = 7; l >= 1; --l)
-        dgrad_layer<2, false>(act, pk + d_img(l), H / 8, ncol0, tid, ws + (WS_C + (size_t)(l - 1) * H) * Mp + m0 * H,
-                              dzp(l), H, nullptr, nullptr);
+        dgrad_layer<2, false, H>(act, pk + d_img(l), H / 8, ncol0, tid, ws + (WS_C + (size_t)(l - 1) * H) * Mp + m0 * H,
+                                 dzp(l), nullptr, nullptr);
     store_tile(act, H, dzp(0), H, tid);
 }
 

@@ -63,21 +63,48 @@ __device__ __forceinline__ void load_a(const float* a_ptr, int kb, f32x4 (&a)[2]
 // the compiler sinks each load to just before its first use and pays the L2 latency of the weight
 // fetch on every block.  (A three-block-deep ring was measured and is not faster.)  The loop is
 // deliberately not unrolled further: twelve fully unrolled layers are ~90 KB of code.
-template <int NT>
+//
+// COPY_COLS != 0 (= 8*kb_count): the loop also copies the tile it reads, act[64][COPY_COLS], to
+// global rows of COPY_COLS floats at gcopy -- one 16-byte piece per thread and loop iteration
+// (64*COPY_COLS/4 pieces = 256 threads * kb_count/2 iterations).  The piece is read from LDS one
+// iteration ahead and stored right after the weight loads of the odd block: vmcnt retires in
+// order, so the first wait that covers the store is the one for the weight loads issued a whole
+// MFMA block later, and no wave ever sits on a store acknowledgement.
+template <int NT, int COPY_COLS = 0>
 __device__ __forceinline__ void mma_layer(const float* act, const float* __restrict__ img, int n_img, int kb_count,
-                                          int ncol0, int lane, f32x16 (&acc)[2][NT]) {
+                                          int ncol0, int lane, f32x16 (&acc)[2][NT], float* __restrict__ gcopy = nullptr,
+                                          int tid = 0) {
     const int r = lane & 31, h = lane >> 5;
     const float* a_ptr = act + r * LDA + 4 * h;
     const float* b_ptr = img + (size_t)(ncol0 + r) * 8 + 4 * h;
     const size_t kb_stride = (size_t)n_img * 8;
     const int last = kb_count - 1;
     f32x4 a0[2], a1[2], b0[NT], b1[NT];
+    constexpr int C4N = COPY_COLS ? COPY_COLS / 4 : 1;       // 16-byte pieces per tile row
+    constexpr int RSTEP = 256 / C4N;                         // tile rows covered per iteration
+    const float* csrc = nullptr;
+    float* cdst = nullptr;
+    f32x4 piece = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (COPY_COLS != 0) {
+        const int row = tid / C4N, c4 = tid % C4N;
+        csrc = act + row * LDA + 4 * c4;
+        cdst = gcopy + (size_t)row * COPY_COLS + 4 * c4;
+        piece = *reinterpret_cast<const f32x4*>(csrc);
+    }
     load_b<NT>(b_ptr, 0, kb_stride, b0);
     load_a(a_ptr, 0, a0);
 #pragma unroll 1
     for (int kb = 0; kb < kb_count; kb += 2) {
         load_b<NT>(b_ptr, kb + 1, kb_stride, b1);
+        if constexpr (COPY_COLS != 0) {
+            __builtin_nontemporal_store(piece, reinterpret_cast<f32x4*>(cdst));
+            cdst += RSTEP * COPY_COLS;
+        }
         load_a(a_ptr, kb + 1, a1);
+        if constexpr (COPY_COLS != 0) {
+            csrc += RSTEP * LDA;
+            if (kb + 2 < kb_count) piece = *reinterpret_cast<const f32x4*>(csrc);
+        }
         __builtin_amdgcn_sched_barrier(0);
         mma_block<NT>(a0, b0, acc);
         __builtin_amdgcn_sched_barrier(0);

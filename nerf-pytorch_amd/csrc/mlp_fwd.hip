@@ -155,7 +155,21 @@ struct FwdArgs {
     float* colors;
     float* density;
     float* ws;
+#ifdef NERF_DIAG
+    unsigned long long* dbg;   // [tile][32]: 100 MHz real-time stamps of wave 0; [30] = XCC id, [31] = HW_ID
+#endif
 };
+
+#ifdef NERF_DIAG
+#define DIAG_STAMP(i)                                                                                   \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64();           \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    } while (0)
+#else
+#define DIAG_STAMP(i) ((void)0)
+#endif
 
 constexpr int XIN_FLOATS = lay::TILE * 8;
 constexpr int FWD_LDS_BYTES = (ACT_FLOATS + XIN_FLOATS + lay::TILE) * 4;
@@ -250,23 +264,20 @@ __device__ __forceinline__ void head_out(const float* act, const float* __restri
 }
 
 
-// one 256 -> 256 layer on the tile: bias, MFMA loop, barrier, epilogue, barrier.
-// Training: the INPUT tile of the layer (the previous layer's output, `in_cols` columns) is copied to
-// the workspace right after the MFMA loop that consumed it, while it is still intact in LDS.  The
-// copy's global stores then have the whole epilogue to complete before the next wait on a weight
-// load: vmcnt retires in order, so a store issued just ahead of a load would make that load's
-// wait cover the store's acknowledgement as well.
-template <int ACT, bool TRAIN>
-__device__ __forceinline__ void hidden_layer(float* act, const float* __restrict__ img, int kb_count,
-                                             const float* __restrict__ bias, int ncol0, int tid, float* gin, int in_cols,
+// one IN_COLS -> 256 layer on the tile: bias, MFMA loop, barrier, epilogue, barrier.
+// Training: the INPUT tile of the layer (the previous layer's output, IN_COLS columns) is copied to
+// the workspace by the MFMA loop that consumes it (mma_layer's COPY_COLS), piece by piece between
+// the MFMA blocks.
+template <int ACT, bool TRAIN, int IN_COLS>
+__device__ __forceinline__ void hidden_layer(float* act, const float* __restrict__ img,
+                                             const float* __restrict__ bias, int ncol0, int tid, float* gin,
                                              float* gcos, unsigned long long* gmask_in = nullptr,
                                              unsigned long long* mask = nullptr) {
     const int lane = tid & 63;
     f32x16 acc[2][2];
     init_bias<2>(acc, bias, ncol0, lane);
-    mma_layer<2>(act, img, lay::H, kb_count, ncol0, lane, acc);
+    mma_layer<2, TRAIN ? IN_COLS : 0>(act, img, lay::H, IN_COLS / 8, ncol0, lane, acc, gin, tid);
     if constexpr (TRAIN) {
-        store_tile(act, in_cols, gin, in_cols, tid);
         if (gmask_in) *gmask_in = *mask;   // ReLU mask word of the input tile's layer, kept in registers until now
     }
     LAYER_SYNC();
@@ -294,54 +305,66 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         return TRAIN ? reinterpret_cast<unsigned long long*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid : nullptr;
     };
 
+#ifdef NERF_DIAG
+    if (a.dbg && tid == 0) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        a.dbg[(size_t)blockIdx.x * 32 + 30] = xcc & 0xf;
+        a.dbg[(size_t)blockIdx.x * 32 + 31] = hwid;
+    }
+#endif
+    DIAG_STAMP(0);
     load_inputs(a, m0, xin, tid);
     __syncthreads();
+    DIAG_STAMP(1);
     encode_pe(act, xin, tid);
     __syncthreads();
+    DIAG_STAMP(2);
 
     const int ncol0 = wave * 64;
     // L0: K 64 (input tile = the position encoding)
     unsigned long long mask = 0ull;   // ReLU bits of the layer just finished; stored after the next MFMA loop
-    hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L0, PE_P / 8, pk + BIAS, ncol0, tid, wsp(WS_PE, PE_P), PE_P, nullptr, nullptr,
-                                  &mask);
+    hidden_layer<ACT_RELU, TRAIN, PE_P>(act, pk + F_L0, pk + BIAS, ncol0, tid, wsp(WS_PE, PE_P), nullptr, nullptr, &mask);
+    DIAG_STAMP(3);
     // L1..L4 (input tile = h(l-1))
 #pragma unroll 1   // one copy of the layer body: unrolled, the kernel outgrows the instruction cache
     for (int l = 1; l <= 4; ++l) {
-        hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
-                                      tid, wsp(WS_H + (size_t)(l - 1) * H, H), H, nullptr, mskp(l - 1), &mask);
+        hidden_layer<ACT_RELU, TRAIN, H>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), pk + BIAS + l * H, ncol0, tid,
+                                         wsp(WS_H + (size_t)(l - 1) * H, H), nullptr, mskp(l - 1), &mask);
+        DIAG_STAMP(3 + l);
     }
     // L5: [h4 | pe] in two passes over the same accumulators
     {
         f32x16 acc[2][2];
         init_bias<2>(acc, pk + BIAS + 5 * H, ncol0, lane);
-        mma_layer<2>(act, pk + F_L5A, H, H / 8, ncol0, lane, acc);
-        if constexpr (TRAIN) {
-            store_tile(act, H, wsp(WS_H + 4 * (size_t)H, H), H, tid);
-            *mskp(4) = mask;
-        }
+        mma_layer<2, TRAIN ? H : 0>(act, pk + F_L5A, H, H / 8, ncol0, lane, acc, wsp(WS_H + 4 * (size_t)H, H), tid);
+        if constexpr (TRAIN) *mskp(4) = mask;
         __syncthreads();
+        DIAG_STAMP(8);
         encode_pe(act, xin, tid);
         __syncthreads();
+        DIAG_STAMP(9);
         mma_layer<2>(act, pk + F_L5B, H, PE_P / 8, ncol0, lane, acc);
         __syncthreads();
         fwd_epilogue<2, ACT_RELU, false>(act, acc, ncol0, lane, nullptr, H, TRAIN ? &mask : nullptr);
         __syncthreads();
+        DIAG_STAMP(10);
     }
     // L6..L8
 #pragma unroll 1   // one copy of the layer body: unrolled, the kernel outgrows the instruction cache
-    for (int l = 6; l <= 8; ++l)
-        hidden_layer<ACT_RELU, TRAIN>(act, pk + F_L6 + (size_t)(l - 6) * img(H, H), H / 8, pk + BIAS + l * H, ncol0,
-                                      tid, wsp(WS_H + (size_t)(l - 1) * H, H), H, nullptr, mskp(l - 1), &mask);
+    for (int l = 6; l <= 8; ++l) {
+        hidden_layer<ACT_RELU, TRAIN, H>(act, pk + F_L6 + (size_t)(l - 6) * img(H, H), pk + BIAS + l * H, ncol0, tid,
+                                         wsp(WS_H + (size_t)(l - 1) * H, H), nullptr, mskp(l - 1), &mask);
+        DIAG_STAMP(5 + l);
+    }
     // L9: 256 feature columns on MFMA, density column on the VALU
     {
         f32x16 acc[2][2];
         init_bias<2>(acc, pk + BIAS + 9 * H, ncol0, lane);
-        mma_layer<2>(act, pk + F_L9, H, H / 8, ncol0, lane, acc);
+        mma_layer<2, TRAIN ? H : 0>(act, pk + F_L9, H, H / 8, ncol0, lane, acc, wsp(WS_H + 8 * (size_t)H, H), tid);
         const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
-        if constexpr (TRAIN) {
-            store_tile(act, H, wsp(WS_H + 8 * (size_t)H, H), H, tid);
-            *mskp(8) = mask;
-        }
+        if constexpr (TRAIN) *mskp(8) = mask;
         if ((tid & 3) == 0) {
             sraw_s[tid >> 2] = s;
             if constexpr (TRAIN) ws[WS_SRAW * Mp + m0 + (tid >> 2)] = s;
@@ -349,26 +372,29 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         __syncthreads();
         fwd_epilogue<2, ACT_NONE, false>(act, acc, ncol0, lane, nullptr, H);
         __syncthreads();
+        DIAG_STAMP(14);
     }
     // L10: [f | de] -> 128, two passes
     {
         const int nc = wave * 32;
         f32x16 acc[2][1];
         init_bias<1>(acc, pk + BIAS10, nc, lane);
-        mma_layer<1>(act, pk + F_L10A, HH, H / 8, nc, lane, acc);
-        if constexpr (TRAIN) store_tile(act, H, wsp(WS_F, H), H, tid);
+        mma_layer<1, TRAIN ? H : 0>(act, pk + F_L10A, HH, H / 8, nc, lane, acc, wsp(WS_F, H), tid);
         __syncthreads();
+        DIAG_STAMP(15);
         encode_de(act, xin, tid);
         __syncthreads();
-        mma_layer<1>(act, pk + F_L10B, HH, DE_P / 8, nc, lane, acc);
-        if constexpr (TRAIN) store_tile(act, DE_P, wsp(WS_DE, DE_P), DE_P, tid);
+        DIAG_STAMP(16);
+        mma_layer<1, TRAIN ? DE_P : 0>(act, pk + F_L10B, HH, DE_P / 8, nc, lane, acc, wsp(WS_DE, DE_P), tid);
         __syncthreads();
         fwd_epilogue<1, ACT_RELU, false>(act, acc, nc, lane, nullptr, HH);
         __syncthreads();
+        DIAG_STAMP(17);
     }
     // L11 + sigmoid, density = relu(raw)
     head_out(act, pk + W11, pk + BIAS11, 1.0f, fmaxf(sraw_s[tid >> 2], 0.0f), m0, a.M, a.colors, a.density, tid);
     if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
+    DIAG_STAMP(18);
 }
 
 template <bool TRAIN>
@@ -411,15 +437,14 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
     const int ncol0 = wave * 64;
 #pragma unroll 1   // one copy of the layer body: unrolled, the kernel outgrows the instruction cache
     for (int l = 1; l <= 7; ++l)
-        hidden_layer<ACT_SIN, TRAIN>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), H / 8, pk + BIAS + l * H, ncol0, tid,
-                                     wsp(WS_H + (size_t)(l - 1) * H, H), H, wsp(WS_C + (size_t)l * H, H));
+        hidden_layer<ACT_SIN, TRAIN, H>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), pk + BIAS + l * H, ncol0, tid,
+                                        wsp(WS_H + (size_t)(l - 1) * H, H), wsp(WS_C + (size_t)l * H, H));
     // feature_remap on MFMA, density branch on the VALU (both read h7)
     {
         f32x16 acc[2][2];
         init_bias<2>(acc, pk + BIAS + 8 * H, ncol0, lane);
-        mma_layer<2>(act, pk + F_FEAT, H, H / 8, ncol0, lane, acc);
+        mma_layer<2, TRAIN ? H : 0>(act, pk + F_FEAT, H, H / 8, ncol0, lane, acc, wsp(WS_H + 7 * (size_t)H, H), tid);
         const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
-        if constexpr (TRAIN) store_tile(act, H, wsp(WS_H + 7 * (size_t)H, H), H, tid);
         if ((tid & 3) == 0) {
             sraw_s[tid >> 2] = s;
             if constexpr (TRAIN) ws[WS_SRAW * Mp + m0 + (tid >> 2)] = s;
@@ -432,13 +457,11 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
         const int nc = wave * 32;
         f32x16 acc[2][1];
         init_bias<1>(acc, pk + BIAS_RGB, nc, lane);
-        mma_layer<1>(act, pk + F_RGBA, HH, H / 8, nc, lane, acc);
-        if constexpr (TRAIN) store_tile(act, H, wsp(WS_F, H), H, tid);
+        mma_layer<1, TRAIN ? H : 0>(act, pk + F_RGBA, HH, H / 8, nc, lane, acc, wsp(WS_F, H), tid);
         __syncthreads();
         encode_de(act, xin, tid);
         __syncthreads();
-        mma_layer<1>(act, pk + F_RGBB, HH, DE_P / 8, nc, lane, acc);
-        if constexpr (TRAIN) store_tile(act, DE_P, wsp(WS_DE, DE_P), DE_P, tid);
+        mma_layer<1, TRAIN ? DE_P : 0>(act, pk + F_RGBB, HH, DE_P / 8, nc, lane, acc, wsp(WS_DE, DE_P), tid);
         __syncthreads();
         fwd_epilogue<1, ACT_SIN, TRAIN>(act, acc, nc, lane, wsp(WS_CG, HH), HH);
         __syncthreads();
@@ -455,7 +478,15 @@ int set_lds(K kernel, int bytes) {
     return NERF_OK;
 }
 
+#ifdef NERF_DIAG
+unsigned long long* g_fwd_dbg = nullptr;
+#endif
+
 }  // namespace
+
+#ifdef NERF_DIAG
+extern "C" void nerf_diag_fwd_stamps(unsigned long long* device_buffer) { g_fwd_dbg = device_buffer; }
+#endif
 
 extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const float* points, const float* dirs,
                             const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near,
@@ -479,6 +510,9 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
     const size_t tiles = mp / lay::TILE;
     NERF_REQUIRE(tiles < (1ull << 31), "nerf_mlp_fwd: too many samples");
     FwdArgs a{packed, M, mp, points, dirs, rays_o, rays_d, t, S, t_per_ray, (float)near, (float)(far - near), colors, density, workspace};
+#ifdef NERF_DIAG
+    a.dbg = g_fwd_dbg;
+#endif
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (model == NERF_MODEL_NERF) {

@@ -62,6 +62,92 @@ __global__ __launch_bounds__(256, 2) void shaped(float* out, const float* __rest
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+
+// Variants of the K loop.  V bit0: A fragments from LDS; bit1: B fragments from global; bit2: the four
+// loads of the next block are spread between the MFMAs of the current one (sched_group_barrier)
+// instead of being issued in one burst at the block boundary.
+template <int V>
+__global__ __launch_bounds__(256, 2) void shaped_v(float* out, const float* __restrict__ w, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 260; i += 256) lds[i] = (float)(i % 97) * 1e-3f;
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+    const float* ap = lds + (lane & 31) * 260 + 4 * (lane >> 5);
+    const float* bp = w + (size_t)(wave * 64 + (lane & 31)) * 8 + 4 * (lane >> 5);
+    f32x4 a0[2], b0[2], a1[2], b1[2];
+    for (int i = 0; i < 2; ++i) for (int k = 0; k < 4; ++k) { a0[i][k] = a1[i][k] = 1e-3f * lane; b0[i][k] = b1[i][k] = 2e-3f * lane; }
+    auto ld = [&](int kb, f32x4 (&a)[2], f32x4 (&b)[2]) {
+        if (V & 2) for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bp + (size_t)kb * 2048 + ni * 256);
+        if (V & 1) for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(ap + mi * 32 * 260 + kb * 8);
+    };
+    auto mm = [&](f32x4 (&a)[2], f32x4 (&b)[2]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if (V & 8)   // accumulators pinned to the AGPR half of the register file
+                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[mi][ni]) : "v"(a[mi][j]), "v"(b[ni][j]));
+                    else
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+                }
+    };
+    auto spread = [&]() {
+        // MFMA x2, DS read, MFMA x2, DS read, MFMA x2, VMEM read, MFMA x2, VMEM read, MFMA x8
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (V & 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (V & 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (V & 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (V & 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    };
+    for (int it = 0; it < iters; ++it) {
+        ld(0, a0, b0);
+#pragma unroll 1
+        for (int kb = 0; kb < 32; kb += 2) {
+            if (V & 4) {
+                ld(kb + 1, a1, b1);
+                mm(a0, b0);
+                spread();
+                __builtin_amdgcn_sched_barrier(0);
+                ld(kb + 2 < 32 ? kb + 2 : kb, a0, b0);
+                mm(a1, b1);
+                spread();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                ld(kb + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                ld(kb + 2 < 32 ? kb + 2 : kb, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (V & 8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results of the asm form are not tracked by the compiler
+    float s = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 16; ++k) s += acc[i][j][k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int V>
+int run_shaped(const char* name, float* out, const float* w, hipEvent_t e0, hipEvent_t e1, int grid) {
+    int iters = 400;
+    CK(hipFuncSetAttribute((const void*)shaped_v<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 66560));
+    shaped_v<V><<<grid, 256, 66560>>>(out, w, 20);
+    CK(hipEventRecord(e0)); shaped_v<V><<<grid, 256, 66560>>>(out, w, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s %8.3f ms  %7.1f TFLOP/s\n", name, ms, (double)grid * 4 * iters * 32 * 16 * 4096.0 / ms / 1e9);
+    return 0;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void layered(float* out, const float* __restrict__ w, int layers, int nimg) {
     // MODE bit0: barriers around an LDS-writing epilogue; bit1: different weight image per layer (nimg images);
@@ -163,6 +249,18 @@ int main() {
             report("MLP-shaped K loop 2 WG/CU", 512.0 * 4 * iters * 32 * 16 * 4096.0, ms);
         }
     }
+    run_shaped<0>("K loop: no loads, 2 WG/CU", out, w, e0, e1, 512);
+    run_shaped<1>("K loop: LDS A only", out, w, e0, e1, 512);
+    run_shaped<2>("K loop: global B only", out, w, e0, e1, 512);
+    run_shaped<3>("K loop: A + B, burst at block boundary", out, w, e0, e1, 512);
+    run_shaped<7>("K loop: A + B, spread between MFMAs", out, w, e0, e1, 512);
+    run_shaped<8>("K loop: no loads, AGPR accumulators", out, w, e0, e1, 512);
+    run_shaped<9>("K loop: LDS A only, AGPR acc", out, w, e0, e1, 512);
+    run_shaped<10>("K loop: global B only, AGPR acc", out, w, e0, e1, 512);
+    run_shaped<11>("K loop: A + B burst, AGPR acc", out, w, e0, e1, 512);
+    run_shaped<3>("K loop: A + B burst, 1 WG/CU", out, w, e0, e1, 256);
+    run_shaped<7>("K loop: A + B spread, 1 WG/CU", out, w, e0, e1, 256);
+    run_shaped<0>("K loop: no loads, 1 WG/CU", out, w, e0, e1, 256);
     run_layered<0>("layered: plain (no epilogue)", out, w, e0, e1, 512);
     run_layered<1>("layered: + barriers + LDS epilogue", out, w, e0, e1, 512);
     run_layered<3>("layered: + 12 weight images", out, w, e0, e1, 512);
