@@ -309,8 +309,8 @@ def main():
                                    + (f"{args.coarse} coarse + ({args.coarse}+{args.fine}) fine = {S} MLP evaluations/ray, "
                                       f"coarse+fine {args.model} MLPs" if hier else
                                       f"{S} samples/ray single pass, one {args.model} MLP")
-                                   + (" (bf16 MFMA, fp32 accumulate)" if args.precision == "bf16" else " (fp32 MFMA)") + f", {args.mode}", "model": args.model, "sampling": args.sampling,
-                       "rays_per_gpu": B, "global_batch": B * world, "mlp_evals_per_ray": S,
+                                   + (" (bf16 MFMA, fp32 accumulate)" if args.precision == "bf16" else " (fp32 MFMA)") + f", {args.mode}", "network": args.model, "sampling": args.sampling,
+                       "rays_per_gpu": B, "rays_per_step": B * world, "mlp_evals_per_ray": S,
                        "parallelism": f"dp{world} ray-sharded, flat-bucket RCCL all-reduce" if world > 1 else "single GPU"},
             "roofline": roof,
             "kernels": kernels,
