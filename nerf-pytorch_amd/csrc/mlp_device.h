@@ -45,10 +45,19 @@ __device__ __forceinline__ void mma_block(const f32x4 (&a)[2], const f32x4 (&b)[
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
 }
 
+// Global operands of the K loops go through buffer instructions: the resource (base, size) lives in
+// SGPRs, the per-lane part of the address is ONE 32-bit VGPR that never changes, and the K block
+// advances in the scalar offset.  Measured on the K loop alone: two global_load_dwordx4 (64-bit
+// address VGPR pairs) per 16 MFMAs cost 5 % of the MFMA rate, two buffer_load_dwordx4 nothing.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
 template <int NT>
-__device__ __forceinline__ void load_b(const float* __restrict__ b_ptr, int kb, size_t kb_stride, f32x4 (&b)[NT]) {
+__device__ __forceinline__ void load_b(__amdgpu_buffer_rsrc_t img, int voff, int kb, int kb_bytes, f32x4 (&b)[NT]) {
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b_ptr + kb * kb_stride + ni * 256);
+    for (int ni = 0; ni < NT; ++ni)
+        b[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(img, voff + ni * 1024, kb * kb_bytes, 0));
 }
 __device__ __forceinline__ void load_a(const float* a_ptr, int kb, f32x4 (&a)[2]) {
 #pragma unroll
@@ -76,29 +85,32 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
                                           int tid = 0) {
     const int r = lane & 31, h = lane >> 5;
     const float* a_ptr = act + r * LDA + 4 * h;
-    const float* b_ptr = img + (size_t)(ncol0 + r) * 8 + 4 * h;
-    const size_t kb_stride = (size_t)n_img * 8;
+    const int kb_bytes = n_img * 32;                                        // one K block of the image
+    const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(img, (unsigned)(kb_count * kb_bytes));
+    const int b_voff = ((ncol0 + r) * 8 + 4 * h) * 4;
     const int last = kb_count - 1;
     f32x4 a0[2], a1[2], b0[NT], b1[NT];
     constexpr int C4N = COPY_COLS ? COPY_COLS / 4 : 1;       // 16-byte pieces per tile row
     constexpr int RSTEP = 256 / C4N;                         // tile rows covered per iteration
     const float* csrc = nullptr;
-    float* cdst = nullptr;
+    __amdgpu_buffer_rsrc_t c_rsrc = b_rsrc;
+    int c_voff = 0, c_soff = 0;
     f32x4 piece = {0.f, 0.f, 0.f, 0.f};
     if constexpr (COPY_COLS != 0) {
         const int row = tid / C4N, c4 = tid % C4N;
         csrc = act + row * LDA + 4 * c4;
-        cdst = gcopy + (size_t)row * COPY_COLS + 4 * c4;
+        c_rsrc = make_rsrc(gcopy, lay::TILE * COPY_COLS * 4);
+        c_voff = (row * COPY_COLS + 4 * c4) * 4;
         piece = *reinterpret_cast<const f32x4*>(csrc);
     }
-    load_b<NT>(b_ptr, 0, kb_stride, b0);
+    load_b<NT>(b_rsrc, b_voff, 0, kb_bytes, b0);
     load_a(a_ptr, 0, a0);
 #pragma unroll 1
     for (int kb = 0; kb < kb_count; kb += 2) {
-        load_b<NT>(b_ptr, kb + 1, kb_stride, b1);
+        load_b<NT>(b_rsrc, b_voff, kb + 1, kb_bytes, b1);
         if constexpr (COPY_COLS != 0) {
-            __builtin_nontemporal_store(piece, reinterpret_cast<f32x4*>(cdst));
-            cdst += RSTEP * COPY_COLS;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, piece), c_rsrc, c_voff, c_soff, 2);  // 2 = nt
+            c_soff += RSTEP * COPY_COLS * 4;
         }
         load_a(a_ptr, kb + 1, a1);
         if constexpr (COPY_COLS != 0) {
@@ -109,7 +121,7 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
         mma_block<NT>(a0, b0, acc);
         __builtin_amdgcn_sched_barrier(0);
         const int kn = min(kb + 2, last);  // clamped: the tail prefetch re-reads the last block
-        load_b<NT>(b_ptr, kn, kb_stride, b0);
+        load_b<NT>(b_rsrc, b_voff, kn, kb_bytes, b0);
         load_a(a_ptr, kn, a0);
         __builtin_amdgcn_sched_barrier(0);
         mma_block<NT>(a1, b1, acc);

@@ -78,8 +78,16 @@ __global__ __launch_bounds__(256, 2) void shaped_v(float* out, const float* __re
     const float* bp = w + (size_t)(wave * 64 + (lane & 31)) * 8 + 4 * (lane >> 5);
     f32x4 a0[2], b0[2], a1[2], b1[2];
     for (int i = 0; i < 2; ++i) for (int k = 0; k < 4; ++k) { a0[i][k] = a1[i][k] = 1e-3f * lane; b0[i][k] = b1[i][k] = 2e-3f * lane; }
+    // V bit4: B fragments through buffer loads (SGPR resource + one 32-bit offset VGPR, K block in the scalar offset)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, 12 * 65536 * 4, 0x00020000);
+    const int voff = ((wave * 64 + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4;
     auto ld = [&](int kb, f32x4 (&a)[2], f32x4 (&b)[2]) {
-        if (V & 2) for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bp + (size_t)kb * 2048 + ni * 256);
+        if (V & 16) {
+            for (int ni = 0; ni < 2; ++ni)
+                b[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + ni * 1024, kb * 8192, 0));
+        } else if (V & 2) {
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bp + (size_t)kb * 2048 + ni * 256);
+        }
         if (V & 1) for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(ap + mi * 32 * 260 + kb * 8);
     };
     auto mm = [&](f32x4 (&a)[2], f32x4 (&b)[2]) {
@@ -258,6 +266,8 @@ int main() {
     run_shaped<9>("K loop: LDS A only, AGPR acc", out, w, e0, e1, 512);
     run_shaped<10>("K loop: global B only, AGPR acc", out, w, e0, e1, 512);
     run_shaped<11>("K loop: A + B burst, AGPR acc", out, w, e0, e1, 512);
+    run_shaped<16>("K loop: buffer-load B only", out, w, e0, e1, 512);
+    run_shaped<17>("K loop: A + buffer-load B, burst", out, w, e0, e1, 512);
     run_shaped<3>("K loop: A + B burst, 1 WG/CU", out, w, e0, e1, 256);
     run_shaped<7>("K loop: A + B spread, 1 WG/CU", out, w, e0, e1, 256);
     run_shaped<0>("K loop: no loads, 1 WG/CU", out, w, e0, e1, 256);
