@@ -152,6 +152,13 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                                              float* __restrict__ gcos, int ldg,
                                              unsigned long long* __restrict__ relu_mask = nullptr) {
     unsigned mlo = 0u, mhi = 0u;
+    // derivative tile: buffer stores (one resource, one lane offset, the element in the constant offset)
+    __amdgpu_buffer_rsrc_t cos_rsrc;
+    int cos_voff = 0;
+    if constexpr (STORE_COS && ACT == ACT_SIN) {
+        cos_rsrc = make_rsrc(gcos, (unsigned)(lay::TILE * ldg * 4));
+        cos_voff = (4 * (lane >> 5) * ldg + ncol0 + (lane & 31)) * 4;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -178,7 +185,9 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                     v = s;
                 }
                 act[row * LDA + col] = v;
-                if constexpr (STORE_COS && ACT == ACT_SIN) gcos[(size_t)row * ldg + col] = c;
+                if constexpr (STORE_COS && ACT == ACT_SIN)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), cos_rsrc, cos_voff,
+                                                          ((32 * mi + (g & 3) + 8 * (g >> 2)) * ldg + 32 * ni) * 4, 0);
             }
         }
     if constexpr (ACT == ACT_RELU && NT == 2) {
@@ -199,6 +208,16 @@ __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                                              const float* dsig_lds, const float* __restrict__ sigw,
                                              unsigned long long bits = 0ull) {
     const unsigned blo = (unsigned)bits, bhi = (unsigned)(bits >> 32);
+    __amdgpu_buffer_rsrc_t h_rsrc;
+    int h_voff = 0;
+    if constexpr (MASK == 1 || MASK == 2) {
+        h_rsrc = make_rsrc(hsrc, (unsigned)(lay::TILE * ldg * 4));
+        h_voff = (4 * (lane >> 5) * ldg + ncol0 + (lane & 31)) * 4;
+    }
+    auto stored = [&](int mi, int ni, int g) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                             h_rsrc, h_voff, ((32 * mi + (g & 3) + 8 * (g >> 2)) * ldg + 32 * ni) * 4, 0));
+    };
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -211,8 +230,8 @@ __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                 const int row = acc_row(mi, g, lane);
                 float v = acc[mi][ni][g];
                 if constexpr (RANK1) v = fmaf(dsig_lds[row], sw, v);
-                if constexpr (MASK == 1) v = hsrc[(size_t)row * ldg + col] > 0.0f ? v : 0.0f;
-                if constexpr (MASK == 2) v = v * hsrc[(size_t)row * ldg + col];
+                if constexpr (MASK == 1) v = stored(mi, ni, g) > 0.0f ? v : 0.0f;
+                if constexpr (MASK == 2) v = v * stored(mi, ni, g);
                 if constexpr (MASK == 3) {
                     const int bit = (mi * NT + ni) * 16 + g;
                     v = (((bit < 32 ? blo : bhi) >> (bit & 31)) & 1u) ? v : 0.0f;
