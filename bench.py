@@ -42,8 +42,8 @@ PEAK_HBM_GBS = 8000.0
 # doubled as the gfx950 note on wide coalesced reads prescribes).  Counters cannot be read from
 # inside this process, so these are constants of the measured build, per sample.
 TRAFFIC_BYTES_PER_SAMPLE = {
-    ("nerf", "mlp_fwd_train"): (2 * 718814 + 11718664) * 1024 / 1048576,   # 12.8 KB: 11.4 KB activations + masks written
-    ("nerf", "mlp_bwd_data"): (2 * 1267473 + 11030687) * 1024 / 1048576,   # 13.2 KB: 10.8 KB layer gradients written
+    ("nerf", "mlp_fwd_train"): (2 * 396256 + 11718656) * 1024 / 1048576,   # 12.2 KB: 11.4 KB activations + masks written
+    ("nerf", "mlp_bwd_data"): (2 * 731632 + 11030586) * 1024 / 1048576,    # 12.2 KB: 10.8 KB layer gradients written
 }
 
 
