@@ -184,10 +184,9 @@ def main():
             raise SystemExit("--precision bf16 is an inference-only mode: add --mode infer")
         for m in models:
             m.set_inference_precision("bf16")
-    flats = [parallel.FlatParameters(m) for m in models]
-    for f in flats:
-        f.broadcast_parameters(0)
-    opts = [parallel.FusedAdam(f, lr=5e-4) for f in flats]
+    flat = parallel.FlatParameters(torch.nn.ModuleList(models))   # one bucket, one all-reduce, one Adam launch
+    flat.broadcast_parameters(0)
+    opt = parallel.FusedAdam(flat, lr=5e-4)
     near, far, B = 2.0, 6.0, args.rays
     S = args.coarse + (args.coarse + args.fine) if hier else args.samples     # MLP evaluations per ray
 
@@ -219,15 +218,13 @@ def main():
         idx = torch.randint(0, n_pool, (B,), device=dev, generator=gen)
         o, d, tgt = rays_o[idx], rays_d[idx], target[idx]
         preds = render(o, d)
-        for opt in opts:
-            opt.zero_grad()
+        opt.zero_grad()
         loss = sum(torch.nn.functional.mse_loss(p, tgt) for p in preds)
         loss.backward()
-        for f, opt in zip(flats, opts):
-            host_sync_for_gloo()
-            f.all_reduce_mean()
-            opt.lr = opt.base_lr * parallel.lr_lambda(step, opt.base_lr, 300.0, 0.1, 1e-4)
-            opt.step()
+        host_sync_for_gloo()
+        flat.all_reduce_mean()
+        opt.lr = opt.base_lr * parallel.lr_lambda(step, opt.base_lr, 300.0, 0.1, 1e-4)
+        opt.step()
         return loss
 
     def infer_step(step):

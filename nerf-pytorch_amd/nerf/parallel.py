@@ -42,8 +42,9 @@ def shared_uniform(num_samples: int, device, generator: Optional[torch.Generator
 
 class FlatParameters:
     """Re-homes a module's parameters (and their .grad) as views of two flat fp32 buffers, in
-    state_dict order.  One all-reduce and one optimizer launch then cover the whole model,
-    while state_dict()/load_state_dict()/torch.optim see the usual 24 tensors.
+    state_dict order.  One all-reduce and one optimizer launch then cover the whole model (or several
+    networks at once: pass a ModuleDict / ModuleList of them), while state_dict()/load_state_dict()/
+    torch.optim see the usual 24 tensors per network.
     For this package's fused modules the backward kernels add their result straight into the gradient
     buffer (no per-tensor accumulation by autograd): drive training with loss.backward(), and zero
     the gradients with zero_grad() of this class or of FusedAdam (never set_to_none)."""
@@ -58,15 +59,26 @@ class FlatParameters:
         self.params = params
         self.flat = torch.empty(total, dtype=dt, device=dev)
         self.grad = torch.zeros(total, dtype=dt, device=dev)
-        off = 0
+        off, start = 0, {}
         for p in params:
             n = p.numel()
             self.flat[off:off + n].copy_(p.detach().reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
+            start[id(p)] = off
             off += n
-        if hasattr(module, "model_id"):
-            module._grad_sink = self.grad
+        # every fused network inside `module` (the module itself, or e.g. the coarse and fine members of a
+        # ModuleDict) gets the slice of the bucket that holds its parameters as its gradient sink
+        self.fused = [m for m in module.modules() if hasattr(m, "model_id")]
+        for m in self.fused:
+            own = list(m.parameters())
+            first, count = start[id(own[0])], sum(p.numel() for p in own)
+            at = first
+            for p in own:
+                if start[id(p)] != at:
+                    raise ValueError("parameters of a fused network are not contiguous in the bucket")
+                at += p.numel()
+            m._grad_sink = self.grad[first:first + count]
 
     def zero_grad(self) -> None:
         """One memset; keeps .grad views attached (do not use set_to_none)."""
@@ -91,8 +103,8 @@ class FlatParameters:
             self._touch()
 
     def _touch(self) -> None:
-        if hasattr(self.module, "invalidate_packed"):
-            self.module.invalidate_packed()
+        for m in self.fused:
+            m.invalidate_packed()
 
 
 class FusedAdam:

@@ -36,37 +36,6 @@ def build_model(model_type: str):
     raise ValueError(f"Invalid model type: {model_type}")
 
 
-class OptimizerGroup:
-    """Several FusedAdam instances (one per network) behind the interface the loop uses."""
-
-    def __init__(self, opts):
-        self.opts = list(opts)
-
-    @property
-    def lr(self):
-        return self.opts[0].lr
-
-    @lr.setter
-    def lr(self, value):
-        for o in self.opts:
-            o.lr = value
-
-    def zero_grad(self):
-        for o in self.opts:
-            o.zero_grad()
-
-    def step(self):
-        for o in self.opts:
-            o.step()
-
-    def state_dict(self):
-        return {"group": [o.state_dict() for o in self.opts]}
-
-    def load_state_dict(self, sd):
-        for o, s in zip(self.opts, sd["group"]):
-            o.load_state_dict(s)
-
-
 def main(argv=None):
     seed = 42
     np.random.seed(seed)
@@ -150,12 +119,9 @@ def main(argv=None):
         sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: max(gamma ** s, lr_min / learning_rate))
         flat = None
     else:
-        flats = [parallel.FlatParameters(n) for n in nets]
-        for f in flats:
-            f.broadcast_parameters(0)
-        fused = [parallel.FusedAdam(f, lr=learning_rate) for f in flats]
-        opt = fused[0] if len(fused) == 1 else OptimizerGroup(fused)
-        flat = flats
+        flat = parallel.FlatParameters(model)   # one bucket for the network, or for the coarse + fine pair
+        flat.broadcast_parameters(0)
+        opt = parallel.FusedAdam(flat, lr=learning_rate)
     start_iter = 0
     if ckpt is not None:
         try:
@@ -192,8 +158,7 @@ def main(argv=None):
             loss.backward()
             loss = mse(preds[-1].detach(), tgt)   # what is logged: the loss of the image that is kept
             if flat is not None:
-                for f in flat:
-                    f.all_reduce_mean()
+                flat.all_reduce_mean()
                 opt.lr = learning_rate * parallel.lr_lambda(step, learning_rate, lr_decay, lr_decay_factor, lr_min)
             opt.step()
             if sched is not None:

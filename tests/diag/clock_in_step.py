@@ -16,8 +16,7 @@ probe.clock_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 models = [NeRF().to(dev) for _ in range(2)]
-flats = [parallel.FlatParameters(m) for m in models]
-opts = [parallel.FusedAdam(f, lr=5e-4) for f in flats]
+opts = [parallel.FusedAdam(parallel.FlatParameters(torch.nn.ModuleList(models)), lr=5e-4)]
 B = 4096
 o = torch.randn(B, 3, device=dev); o = 4 * o / o.norm(dim=1, keepdim=True)
 d = torch.nn.functional.normalize(-o + 0.3 * torch.randn(B, 3, device=dev), dim=1)

@@ -393,7 +393,7 @@ def test_flat_bucket_receives_gradients_directly(hip):
     loss().backward()                                   # plain autograd path, three chunks accumulate
     ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
     flat = parallel.FlatParameters(model)
-    assert model._grad_sink is flat.grad
+    assert model._grad_sink.data_ptr() == flat.grad.data_ptr() and model._grad_sink.numel() == flat.grad.numel()
     flat.zero_grad()
     loss().backward()
     assert rel(flat.grad, ref) < 1e-6 and float(flat.grad.abs().max()) > 0
@@ -408,6 +408,55 @@ def test_flat_bucket_receives_gradients_directly(hip):
     loss().backward()
     got = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     assert rel(got, ref) < 1e-6 and float(flat.grad.abs().max()) == 0.0
+
+
+def test_one_bucket_for_a_coarse_fine_pair(hip):
+    """One FlatParameters over a ModuleDict of two networks: each network's backward adds into its own slice
+    of the shared bucket; the values equal those of two separate per-network autograd runs, and one fused
+    Adam launch over the pair equals two launches over the halves."""
+    from nerf import parallel
+    from nerf.rendering import render_nerf_hierarchical
+    coarse, _ = make_model("nerf")
+    fine, _ = make_model("nerf")
+    with torch.no_grad():
+        for p in fine.parameters():
+            p.mul_(1.01)
+    pair = torch.nn.ModuleDict({"coarse": coarse, "fine": fine})
+    o, d = rays(80, 81)
+    o, d = o.to(DEV), d.to(DEV)
+    u = [torch.rand(16, generator=torch.Generator().manual_seed(82)).to(DEV)]
+    uf = [torch.rand(80, 24, generator=torch.Generator().manual_seed(83)).to(DEV)]
+    tgt = torch.rand(80, 3, generator=torch.Generator().manual_seed(84)).to(DEV)
+
+    def loss():
+        rc, rf = render_nerf_hierarchical(coarse, fine, o, d, 2.0, 6.0, 16, 24, device=DEV, u=u, u_fine=uf)
+        return torch.nn.functional.mse_loss(rc, tgt) + torch.nn.functional.mse_loss(rf, tgt)
+
+    loss().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in pair.parameters()]).clone()
+    before = torch.cat([p.detach().reshape(-1) for p in pair.parameters()]).clone()
+    flat = parallel.FlatParameters(pair)
+    n = sum(p.numel() for p in coarse.parameters())
+    assert coarse._grad_sink.data_ptr() == flat.grad.data_ptr()
+    assert fine._grad_sink.data_ptr() == flat.grad.data_ptr() + 4 * n and fine._grad_sink.numel() == n
+    flat.zero_grad()
+    loss().backward()
+    assert rel(flat.grad[:n], ref[:n]) < 1e-6 and rel(flat.grad[n:], ref[n:]) < 1e-6
+    assert float(flat.grad[:n].abs().max()) > 0 and float(flat.grad[n:].abs().max()) > 0
+    opt = parallel.FusedAdam(flat, lr=1e-3)
+    opt.step()
+    m = 0.1 * ref                                       # first Adam step: p -= lr * m_hat / (sqrt(v_hat) + eps)
+    want = before - 1e-3 * (m / 0.1) / ((0.001 * ref * ref / 0.001).sqrt() + 1e-8)
+    assert rel(flat.flat, want) < 1e-5
+    # the packed weight images of both networks follow the update
+    with torch.no_grad():
+        rc1, rf1 = render_nerf_hierarchical(coarse, fine, o, d, 2.0, 6.0, 16, 24, device=DEV, u=u, u_fine=uf)
+    ref_pair = [type(coarse)().to(DEV), type(fine)().to(DEV)]
+    ref_pair[0].load_state_dict(coarse.state_dict())
+    ref_pair[1].load_state_dict(fine.state_dict())
+    with torch.no_grad():
+        rc2, rf2 = render_nerf_hierarchical(ref_pair[0], ref_pair[1], o, d, 2.0, 6.0, 16, 24, device=DEV, u=u, u_fine=uf)
+    assert torch.equal(rc1, rc2) and torch.equal(rf1, rf2)
 
 
 # ----------------------------------------------------------------------------- full-size properties
