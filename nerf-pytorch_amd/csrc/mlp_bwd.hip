@@ -196,7 +196,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TK; ++j) acc[i][j] = splat16(0.0f);
-    float bsum = 0.0f;
 
     // the next chunk goes global -> LDS directly (no staging registers, no ds_write pass).  A buffer is
     // [32][NW] of dY followed by [32][KW] of X; 16-byte piece v of either part lands at byte 16*v of
@@ -220,13 +219,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.q + (size_t)chunk * 32 + tid),
                                              (__attribute__((address_space(3))) void*)(buf + 32 * ROWF), 4, 0, 0);
     };
-    // bias column sums: all 512 threads take part, thread (grp, col) adds rows grp*BROWS.. of column col
-    constexpr int BGRP = 512 / NW, BROWS = 32 / BGRP;
-    const int bcol = tid % NW, brow0 = (tid / NW) * BROWS;
-    // rank-1 row: thread (grp, col) adds q[row] * X[row][col] over rows grp*XROWS..
-    constexpr int XGRP = 512 / KW, XROWS = 32 / XGRP;
-    const int xcol = tid % KW, xrow0 = (tid / KW) * XROWS;
-    float xsum = 0.0f, qsum = 0.0f;
+    // bias column sums: all 512 threads take part, thread (grp, c4) adds rows grp*BROWS.. of the four
+    // columns 4*c4.. (16-byte LDS reads: a quarter of the LDS instructions of a column-per-thread split)
+    constexpr int BGRP = 512 / (NW / 4), BROWS = 32 / BGRP;
+    const int bc4 = tid % (NW / 4), bgrp = tid / (NW / 4), brow0 = bgrp * BROWS;
+    f32x4 bsum4 = {0.f, 0.f, 0.f, 0.f};
+    // rank-1 row: thread (grp, c4) adds q[row] * X[row][4*c4..] over rows grp*XROWS..
+    constexpr int XGRP = 512 / (KW / 4), XROWS = 32 / XGRP;
+    static_assert(BROWS >= 1 && (!RANK1 || XROWS == 4), "row split of the column sums");
+    const int xc4 = tid % (KW / 4), xgrp = tid / (KW / 4), xrow0 = xgrp * XROWS;
+    f32x4 xsum4 = {0.f, 0.f, 0.f, 0.f};
+    float qsum = 0.0f;
 
     if (c0 < c1) stage(c0, smem);
     __syncthreads();  // also waits for the loads above (an LDS-DMA counts on vmcnt)
@@ -281,14 +284,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
         }
         if (a.bslab) {
 #pragma unroll
-            for (int s = 0; s < BROWS; ++s) bsum += buf[(brow0 + s) * NW + bcol];
+            for (int s = 0; s < BROWS; ++s) bsum4 += *reinterpret_cast<const f32x4*>(buf + (brow0 + s) * NW + 4 * bc4);
         }
-        if (RANK1) {
+        if constexpr (RANK1) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(buf + 32 * ROWF + xrow0);   // XROWS == 4 consecutive rows
 #pragma unroll
-            for (int s = 0; s < XROWS; ++s) {
-                const float qv = buf[32 * ROWF + xrow0 + s];
-                xsum = fmaf(qv, buf[32 * NW + (xrow0 + s) * KW + xcol], xsum);
-                qsum += qv;
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(buf + 32 * NW + (xrow0 + s) * KW + 4 * xc4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xsum4[e] = fmaf(qv[s], xv[e], xsum4[e]);
+                qsum += qv[s];
             }
         }
         __syncthreads();
@@ -307,10 +312,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
             }
     }
     // the last barrier of the loop has passed: the staging buffers are free for the cross-group sums
-    if (a.bslab) smem[tid] = bsum;
-    if (RANK1) {
-        smem[512 + tid] = xsum;
-        if (xcol == 0) smem[1024 + tid / KW] = qsum;
+    // (2048 floats of bias partials [BGRP][NW], 2048 of rank-1 partials [XGRP][KW], XGRP of q sums)
+    static_assert(2 * BUF >= 4096 + 64, "staging buffers too small for the partial sums");
+    if (a.bslab) *reinterpret_cast<f32x4*>(smem + bgrp * NW + 4 * bc4) = bsum4;
+    if constexpr (RANK1) {
+        *reinterpret_cast<f32x4*>(smem + 2048 + xgrp * KW + 4 * xc4) = xsum4;
+        if (xc4 == 0) smem[4096 + xgrp] = qsum;
     }
     __syncthreads();
     if (a.bslab && tid < NW) {
@@ -319,16 +326,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
         for (int g = 1; g < BGRP; ++g) t += smem[tid + g * NW];
         a.bslab[(size_t)bid * NW + tid] = t;
     }
-    if (RANK1 && tid < KW) {
-        float t = smem[512 + tid];
+    if constexpr (RANK1) {
+        if (tid < KW) {
+            float t = smem[2048 + tid];
 #pragma unroll
-        for (int g = 1; g < XGRP; ++g) t += smem[512 + tid + g * KW];
-        a.qslab[(size_t)bid * KW + tid] = t;
-        if (tid == 0) {
-            float u = smem[1024];
+            for (int g = 1; g < XGRP; ++g) t += smem[2048 + tid + g * KW];
+            a.qslab[(size_t)bid * KW + tid] = t;
+            if (tid == 0) {
+                float u = smem[4096];
 #pragma unroll
-            for (int g = 1; g < XGRP; ++g) u += smem[1024 + g];
-            a.qbslab[bid] = u;
+                for (int g = 1; g < XGRP; ++g) u += smem[4096 + g];
+                a.qbslab[bid] = u;
+            }
         }
     }
 }
