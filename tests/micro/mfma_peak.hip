@@ -175,8 +175,13 @@ __global__ __launch_bounds__(256, 2) void layered(float* out, const float* __res
             float bias = (MODE & 4) ? img[wave * 64 + 32 * j + (lane & 31)] : 0.f;
             for (int k = 0; k < 16; ++k) acc[i][j][k] = bias;
         }
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, 65536 * 4, 0x00020000);
+        const int voff = ((wave * 64 + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4;
         auto ld = [&](int kb, f32x4 (&a)[2], f32x4 (&b)[2]) {
-            for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(bp + (size_t)kb * 2048 + ni * 256);
+            for (int ni = 0; ni < 2; ++ni) {
+                if (MODE & 8) b[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + ni * 1024, kb * 8192, 0));
+                else b[ni] = *reinterpret_cast<const f32x4*>(bp + (size_t)kb * 2048 + ni * 256);
+            }
             for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(ap + mi * 32 * 260 + kb * 8);
         };
         auto mm = [&](f32x4 (&a)[2], f32x4 (&b)[2]) {
@@ -212,6 +217,74 @@ __global__ __launch_bounds__(256, 2) void layered(float* out, const float* __res
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = s + lds[threadIdx.x];
+}
+
+// The layered kernel on 32-sample tiles: wave = 32 rows x 64 columns (2 accumulator tiles), 33 KB of LDS,
+// four workgroups per CU (4 waves per SIMD) instead of two 64-sample ones.  B fragments through buffer loads.
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void layered32(float* out, const float* __restrict__ w, int layers, int nimg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 32 * 260; i += 256) lds[i] = (float)(i % 97) * 1e-3f;
+    __syncthreads();
+    const float* ap = lds + (lane & 31) * 260 + 4 * (lane >> 5);
+    const int voff = ((wave * 64 + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4;
+    f32x4 a0, b0[2], a1, b1[2];
+    float s = 0;
+    for (int l = 0; l < layers; ++l) {
+        const float* img = w + ((MODE & 2) ? (size_t)((l + blockIdx.x) % nimg) * 65536 : 0);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, 65536 * 4, 0x00020000);
+        f32x16 acc[2];
+        for (int j = 0; j < 2; ++j) {
+            float bias = (MODE & 4) ? img[wave * 64 + 32 * j + (lane & 31)] : 0.f;
+            for (int k = 0; k < 16; ++k) acc[j][k] = bias;
+        }
+        auto ld = [&](int kb, f32x4& a, f32x4 (&b)[2]) {
+            for (int ni = 0; ni < 2; ++ni)
+                b[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + ni * 1024, kb * 8192, 0));
+            a = *reinterpret_cast<const f32x4*>(ap + kb * 8);
+        };
+        auto mm = [&](f32x4& a, f32x4 (&b)[2]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[ni][j], acc[ni], 0, 0, 0);
+        };
+        ld(0, a0, b0);
+#pragma unroll 1
+        for (int kb = 0; kb < 32; kb += 2) {
+            ld(kb + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            ld(kb + 2 < 32 ? kb + 2 : kb, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE & 1) {
+            __syncthreads();
+            for (int ni = 0; ni < 2; ++ni) for (int g = 0; g < 16; ++g) {
+                int row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5), col = wave * 64 + 32 * ni + (lane & 31);
+                lds[row * 260 + col] = fmaxf(acc[ni][g], 0.f) * 1e-3f;
+            }
+            __syncthreads();
+        } else {
+            for (int j = 0; j < 2; ++j) for (int k = 0; k < 16; ++k) s += acc[j][k];
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = s + lds[threadIdx.x];
+}
+
+template <int MODE>
+int run_layered32(const char* name, float* out, const float* w, hipEvent_t e0, hipEvent_t e1, int grid) {
+    int layers = 400;
+    CK(hipFuncSetAttribute((const void*)layered32<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 33280));
+    layered32<MODE><<<grid, 256, 33280>>>(out, w, 20, 12);
+    CK(hipEventRecord(e0)); layered32<MODE><<<grid, 256, 33280>>>(out, w, layers, 12); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s %8.3f ms  %7.1f TFLOP/s\n", name, ms, (double)grid * 4 * layers * 32 * 8 * 4096.0 / ms / 1e9);
+    return 0;
 }
 
 template <int MODE>
@@ -271,6 +344,11 @@ int main() {
     run_shaped<3>("K loop: A + B burst, 1 WG/CU", out, w, e0, e1, 256);
     run_shaped<7>("K loop: A + B spread, 1 WG/CU", out, w, e0, e1, 256);
     run_shaped<0>("K loop: no loads, 1 WG/CU", out, w, e0, e1, 256);
+    run_layered<15>("layered 64-row: all, buffer loads, 2 WG/CU", out, w, e0, e1, 512);
+    run_layered<8>("layered 64-row: plain, buffer loads", out, w, e0, e1, 512);
+    run_layered32<7>("layered 32-row tiles: all, 4 WG/CU", out, w, e0, e1, 1024);
+    run_layered32<7>("layered 32-row tiles: all, 2 WG/CU", out, w, e0, e1, 512);
+    run_layered32<0>("layered 32-row tiles: plain, 4 WG/CU", out, w, e0, e1, 1024);
     run_layered<0>("layered: plain (no epilogue)", out, w, e0, e1, 512);
     run_layered<1>("layered: + barriers + LDS epilogue", out, w, e0, e1, 512);
     run_layered<3>("layered: + 12 weight images", out, w, e0, e1, 512);
