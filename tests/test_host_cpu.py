@@ -131,3 +131,28 @@ def test_lr_schedule_and_shard_helpers():
     assert parallel.shard_slice(32768, 3, 8) == slice(12288, 16384)
     with pytest.raises(ValueError):
         parallel.shard_slice(10, 0, 3)
+
+
+def test_flat_bucket_slices_for_several_networks():
+    """parallel.FlatParameters over a container: parameters become views of one buffer in state_dict order and
+    every fused network gets the slice of the gradient bucket that holds its own parameters (host logic only)."""
+    import torch
+    from nerf import parallel
+    from nerf.models import NeRF, Siren
+    pair = torch.nn.ModuleDict({"coarse": NeRF(), "fine": Siren()})
+    before = {k: v.clone() for k, v in pair.state_dict().items()}
+    flat = parallel.FlatParameters(pair)
+    n_c = sum(p.numel() for p in pair["coarse"].parameters())
+    n_f = sum(p.numel() for p in pair["fine"].parameters())
+    assert (n_c, n_f) == (661636, 564356) and flat.flat.numel() == n_c + n_f
+    assert pair["coarse"]._grad_sink.data_ptr() == flat.grad.data_ptr() and pair["coarse"]._grad_sink.numel() == n_c
+    assert pair["fine"]._grad_sink.data_ptr() == flat.grad.data_ptr() + 4 * n_c and pair["fine"]._grad_sink.numel() == n_f
+    for k, v in pair.state_dict().items():               # values unchanged, storage shared with the bucket
+        assert torch.equal(v, before[k])
+    off = 0
+    for p in pair.parameters():
+        assert p.data_ptr() == flat.flat.data_ptr() + 4 * off and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * off
+        off += p.numel()
+    flat.grad.fill_(1.0)
+    flat.zero_grad()
+    assert float(flat.grad.abs().max()) == 0.0 and len(flat.fused) == 2
