@@ -143,8 +143,8 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[2][NT], const float* __r
 __device__ __forceinline__ int acc_row(int mi, int g, int lane) { return 32 * mi + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5); }
 
 // Forward epilogue: activation, write the tile back to LDS as the next layer's input.
-// The post-activation tile itself goes to the workspace afterwards through store_tile
-// (whole rows, 16 B per lane); for sine layers (training) the derivative cos(z) has no LDS
+// The post-activation tile itself goes to the workspace later, from LDS, inside the next MFMA loop
+// that reads it (mma_layer's COPY_COLS); for sine layers (training) the derivative cos(z) has no LDS
 // home and is stored from the accumulator layout: gcos = row 0 of this tile, [64][ldg].
 // relu_mask (may be NULL): receives this lane's 64 (v > 0) bits, accumulator order.
 template <int NT, int ACT, bool STORE_COS>
@@ -197,7 +197,7 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
 
 // Backward epilogue: dX = acc (+ rank-1 term) times the activation derivative, written to
 // LDS (next layer's dY); the tile is copied to the backward workspace (for the weight gradient)
-// later, row-wise, after the next MFMA loop has consumed it.
+// by the next MFMA loop, which reads it (mma_layer's COPY_COLS).
 //   MASK 1: derivative = (hsrc > 0)         (ReLU; hsrc = the stored post-activation input)
 //   MASK 2: derivative = hsrc               (sine; hsrc = stored w0*cos(w0 z))
 //   MASK 3: derivative = bit of `bits`      (ReLU; the forward's per-lane mask word)
