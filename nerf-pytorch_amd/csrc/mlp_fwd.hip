@@ -272,17 +272,32 @@ template <int ACT, bool TRAIN, int IN_COLS>
 __device__ __forceinline__ void hidden_layer(float* act, const float* __restrict__ img,
                                              const float* __restrict__ bias, int ncol0, int tid, float* gin,
                                              float* gcos, unsigned long long* gmask_in = nullptr,
-                                             unsigned long long* mask = nullptr) {
+                                             unsigned long long* mask = nullptr, unsigned long long* stamps = nullptr) {
     const int lane = tid & 63;
     f32x16 acc[2][2];
+#ifdef NERF_DIAG
+#define LAYER_STAMP(i)                                                         \
+    do {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        if (stamps && tid == 0) stamps[i] = wall_clock64();                    \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+    } while (0)
+#else
+#define LAYER_STAMP(i) ((void)0)
+#endif
+    LAYER_STAMP(0);
     init_bias<2>(acc, bias, ncol0, lane);
     mma_layer<2, TRAIN ? IN_COLS : 0>(act, img, lay::H, IN_COLS / 8, ncol0, lane, acc, gin, tid);
     if constexpr (TRAIN) {
         if (gmask_in) *gmask_in = *mask;   // ReLU mask word of the input tile's layer, kept in registers until now
     }
+    LAYER_STAMP(1);
     LAYER_SYNC();
+    LAYER_STAMP(2);
     fwd_epilogue<2, ACT, TRAIN>(act, acc, ncol0, lane, gcos, lay::H, TRAIN ? mask : nullptr);
+    LAYER_STAMP(3);
     LAYER_SYNC();
+    LAYER_STAMP(4);
 }
 
 template <bool TRAIN>
@@ -330,8 +345,13 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
     // L1..L4 (input tile = h(l-1))
 #pragma unroll 1   // one copy of the layer body: unrolled, the kernel outgrows the instruction cache
     for (int l = 1; l <= 4; ++l) {
+#ifdef NERF_DIAG
+        unsigned long long* layer_stamps = (a.dbg && l == 2) ? a.dbg + (size_t)blockIdx.x * 32 + 20 : nullptr;
+#else
+        unsigned long long* layer_stamps = nullptr;
+#endif
         hidden_layer<ACT_RELU, TRAIN, H>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), pk + BIAS + l * H, ncol0, tid,
-                                         wsp(WS_H + (size_t)(l - 1) * H, H), nullptr, mskp(l - 1), &mask);
+                                         wsp(WS_H + (size_t)(l - 1) * H, H), nullptr, mskp(l - 1), &mask, layer_stamps);
         DIAG_STAMP(3 + l);
     }
     // L5: [h4 | pe] in two passes over the same accumulators

@@ -45,6 +45,12 @@ for i, n in enumerate(names):
     dur = T[:, i + 1] - T[:, i]
     print(f"  {n:14s} mean {dur.mean():7.2f} us   p10 {np.percentile(dur, 10):7.2f}  p90 {np.percentile(dur, 90):7.2f}")
 
+L = g[:, 20:25].astype(np.float64) * 0.01
+print("inside layer 2 (wave 0): bias + MFMA loop %.2f us, wait at barrier %.2f, epilogue %.2f, wait at barrier %.2f" % tuple(
+    (L[:, i + 1] - L[:, i]).mean() for i in range(4)))
+print("   p10/p90: loop %.2f/%.2f  epilogue %.2f/%.2f" % (np.percentile(L[:, 1] - L[:, 0], 10), np.percentile(L[:, 1] - L[:, 0], 90),
+                                                          np.percentile(L[:, 3] - L[:, 2], 10), np.percentile(L[:, 3] - L[:, 2], 90)))
+
 # per compute unit: how many resident tiles, and how many of them inside an MFMA phase, over time
 MFMA = [(2, 8), (9, 15), (16, 17)]               # stamp index ranges that contain MFMA loops (with their epilogues)
 cu_key = (g[:, 30] << 16) | (g[:, 31] & 0xff00)
