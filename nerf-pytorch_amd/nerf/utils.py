@@ -1,7 +1,11 @@
 """Run-time plumbing around the render path: `key = value` config files, timestamps,
 checkpoint files and the per-iteration log line.  Same function names, file format and
 checkpoint keys as the reference's nerf/utils.py (:9-34 parse_config, :37-47 format_elapsed_time,
-:50-63 save_checkpoint, :66-77 log_training_metrics), so its configs and .pth files interchange."""
+:50-63 save_checkpoint, :66-77 log_training_metrics) and the same call signatures, so the reference's
+train.py / eval.py call them unchanged.  Config files interchange; of a checkpoint only
+`model_state_dict` (and `step`, `model_type`) interchanges in general: the optimizer / scheduler entries
+are those of whatever optimizer wrote the file (torch.optim.Adam + LambdaLR, or this package's FusedAdam,
+whose state is not a torch.optim state_dict)."""
 from __future__ import annotations
 
 import datetime as _dt
@@ -58,11 +62,28 @@ def save_checkpoint(step, model, optimizer, scheduler, save_path, model_type) ->
     return target
 
 
-def log_training_metrics(step, current_lr, loss, start_time, writer: Optional[object] = None) -> str:
-    """The per-iteration report line; also mirrored to a TensorBoard-like writer if one is given."""
-    mse = float(loss)
+def _emit(line: str) -> None:
+    """tqdm.write when tqdm is importable (keeps a progress bar intact, as the reference does), else print."""
+    try:
+        from tqdm import tqdm
+    except ImportError:
+        print(line, flush=True)
+    else:
+        tqdm.write(line)
+
+
+def log_training_metrics(step, scheduler, loss, start_time, writer: Optional[object] = None) -> str:
+    """Write the per-iteration report line and mirror loss / psnr / learning_rate to a TensorBoard-like
+    writer (reference utils.py:66-77, called as train.py:187 does: `(step, scheduler, loss, start_time,
+    writer)`).  `scheduler` is anything with get_last_lr() (torch LR schedulers) or the current rate as
+    a float; `loss` a one-element tensor (synchronises through .item(), like the reference) or a float;
+    `writer` may be None.  The line is also returned."""
+    current_lr = float(scheduler.get_last_lr()[0]) if hasattr(scheduler, "get_last_lr") else float(scheduler)
+    mse = float(loss.item()) if hasattr(loss, "item") else float(loss)
     psnr = mse_to_psnr(mse)
+    line = "[%s] [Iter %07d] LR: %.6f MSE: %.4f PSNR: %.2f" % (format_elapsed_time(start_time), step, current_lr, mse, psnr)
+    _emit(line)
     if writer is not None:
         for tag, value in (("loss", mse), ("psnr", psnr), ("learning_rate", current_lr)):
             writer.add_scalar(tag, value, step)
-    return "[%s] [Iter %07d] LR: %.6f MSE: %.4f PSNR: %.2f" % (format_elapsed_time(start_time), step, current_lr, mse, psnr)
+    return line

@@ -167,7 +167,7 @@ def main(argv=None):
                 learning_rate * parallel.lr_lambda(step + 1, learning_rate, lr_decay, lr_decay_factor, lr_min)
 
             if rank == 0 and step % log_interval == 0:
-                print(log_training_metrics(step, cur_lr, loss.item(), start_time, writer), flush=True)
+                log_training_metrics(step, sched if sched is not None else cur_lr, loss, start_time, writer)
             if rank == 0 and step % save_interval == 0 and 0 < step < num_iters - 1:
                 name = save_checkpoint(step, model, opt, sched, save_path, model_type)
                 print(f"[{format_elapsed_time(start_time)}] Model saved to {name} at iteration {step}")
