@@ -195,7 +195,8 @@ def main():
     rays_o, rays_d, target = make_rays(views_per_rank, args.res, args.res, dev, seed=42 + rank)
     n_pool = rays_o.shape[0]
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    ugen = torch.Generator(device=dev).manual_seed(999)  # same seed on all ranks; also broadcast
+    ugen = torch.Generator(device=dev).manual_seed(999)  # same seed on all ranks: identical draws, no collective
+    parallel.check_shared_draws(dev, ugen)
 
     def host_sync_for_gloo():
         # rehearsal backend only: gloo stages device tensors through the host and, with several ranks
@@ -222,7 +223,7 @@ def main():
         loss = sum(torch.nn.functional.mse_loss(p, tgt) for p in preds)
         loss.backward()
         host_sync_for_gloo()
-        flat.all_reduce_mean()
+        flat.all_reduce_mean(scale_in_optimizer=True)   # 1/world rides in the Adam kernel's gradient scale
         opt.lr = opt.base_lr * parallel.lr_lambda(step, opt.base_lr, 300.0, 0.1, 1e-4)
         opt.step()
         return loss

@@ -6,7 +6,8 @@ The reference has no distributed code.  Equivalence to its single-process step
 (train.py:166-183): MSELoss is a mean over B*3, so equal contiguous ray slices + gradient
 averaging reproduce the single-process gradient up to summation order -- provided every
 rank uses the same uniform draw u[S], because the reference shares one t-vector across the
-whole batch (rendering.py:26,59-62).  `shared_uniform` provides that draw.
+whole batch (rendering.py:26,59-62).  `shared_uniform` provides that draw from identically seeded
+per-rank generators: no collective per draw, one broadcast at start-up to verify the agreement.
 """
 from __future__ import annotations
 
@@ -32,12 +33,70 @@ def shard_slice(n: int, rank: int, world_size: int) -> slice:
     return slice(rank * per, (rank + 1) * per)
 
 
+_SHARED_SEED = 0x5EED0A11
+_shared_generators = {}
+
+
+def shared_generator(device, seed: int = _SHARED_SEED) -> torch.Generator:
+    """The generator on `device` that shared_uniform draws from when none is passed: seeded with the same
+    constant on every rank, so the ranks' draw sequences are identical without any communication."""
+    key = (str(torch.device(device)), seed)
+    if key not in _shared_generators:
+        _shared_generators[key] = torch.Generator(device=device).manual_seed(seed)
+    return _shared_generators[key]
+
+
 def shared_uniform(num_samples: int, device, generator: Optional[torch.Generator] = None) -> torch.Tensor:
-    """The per-chunk uniform draw, identical on every rank: rank 0 draws, everyone receives."""
-    u = torch.rand(num_samples, device=device, generator=generator)
+    """The per-chunk uniform draw, identical on every rank.  Every rank draws from its own generator;
+    the generators carry the same seed and are advanced by the same calls, so no collective is needed
+    (a broadcast per chunk would be one latency-bound collective per chunk and step).  Pass the same
+    seeded generator on all ranks, or none to use shared_generator(device); check_shared_draws()
+    verifies the agreement once."""
+    if generator is None:
+        generator = shared_generator(device)
+    return torch.rand(num_samples, device=device, generator=generator)
+
+
+def check_shared_draws(device, generator: Optional[torch.Generator] = None, n: int = 64) -> None:
+    """One broadcast at start-up: raises on every rank's own comparison if its generator is not in
+    step with rank 0's.  Consumes n draws on every rank alike."""
+    mine = shared_uniform(n, device, generator)
     if world()[1] > 1:
-        dist.broadcast(u, src=0)
-    return u
+        ref = mine.clone()
+        dist.broadcast(ref, src=0)
+        if not torch.equal(ref, mine):
+            raise RuntimeError("data-parallel ranks do not share the stratified-sampling draw: seed the "
+                               "generator passed to shared_uniform identically on every rank")
+
+
+def broadcast_module_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    """Rank src's parameters to every rank (for modules that are not re-homed by FlatParameters)."""
+    if world()[1] > 1:
+        with torch.no_grad():
+            for p in module.parameters():
+                dist.broadcast(p.data, src=src)
+        for m in module.modules():
+            if hasattr(m, "invalidate_packed"):
+                m.invalidate_packed()
+
+
+def all_reduce_module_grads(module: torch.nn.Module) -> None:
+    """Average the per-tensor .grad of a module over ranks through ONE flattened all-reduce (the path of
+    torch.optim optimizers, whose zero_grad detaches .grad from any flat bucket)."""
+    ws = world()[1]
+    if ws <= 1:
+        return
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if len(grads) != sum(1 for _ in module.parameters()):
+        raise RuntimeError("all_reduce_module_grads: a parameter has no gradient on this rank")
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / ws)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
 
 
 class FlatParameters:
@@ -70,6 +129,7 @@ class FlatParameters:
         # every fused network inside `module` (the module itself, or e.g. the coarse and fine members of a
         # ModuleDict) gets the slice of the bucket that holds its parameters as its gradient sink
         self.fused = [m for m in module.modules() if hasattr(m, "model_id")]
+        self.pending_scale = 1.0   # factor the optimizer still has to apply to the bucket (see all_reduce_mean)
         for m in self.fused:
             own = list(m.parameters())
             first, count = start[id(own[0])], sum(p.numel() for p in own)
@@ -83,6 +143,7 @@ class FlatParameters:
     def zero_grad(self) -> None:
         """One memset; keeps .grad views attached (do not use set_to_none)."""
         self.grad.zero_()
+        self.pending_scale = 1.0
         off = 0
         for p in self.params:  # re-attach in case something replaced .grad
             n = p.numel()
@@ -90,12 +151,18 @@ class FlatParameters:
                 p.grad = self.grad[off:off + n].view(p.shape)
             off += n
 
-    def all_reduce_mean(self) -> None:
-        """Average the gradient bucket over ranks (no-op for a single process)."""
+    def all_reduce_mean(self, scale_in_optimizer: bool = False) -> None:
+        """Average the gradient bucket over ranks (no-op for a single process): one SUM all-reduce, then
+        the 1/world factor -- applied here by one more elementwise launch, or, with scale_in_optimizer,
+        left in `pending_scale` for FusedAdam.step(), which folds it into the Adam kernel's gradient
+        scale (the bucket then holds the SUM until zero_grad)."""
         _, ws = world()
         if ws > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
-            self.grad.mul_(1.0 / ws)
+            if scale_in_optimizer:
+                self.pending_scale *= 1.0 / ws
+            else:
+                self.grad.mul_(1.0 / ws)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if world()[1] > 1:
@@ -129,7 +196,7 @@ class FusedAdam:
     def step(self) -> None:
         self.step_count += 1
         self._hip.adam_step(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                            self.betas[0], self.betas[1], self.eps)
+                            self.betas[0], self.betas[1], self.eps, grad_scale=self.flat.pending_scale)
         self.flat._touch()
 
     def state_dict(self) -> dict:

@@ -102,6 +102,11 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
     rays_d = _f32c(rays_d.to(device))
     if not rays_o.is_cuda:
         raise RuntimeError("render_nerf: this build has no CPU path; pass device='cuda'")
+    if rays_o.shape[0] == 0:   # nothing to render (the reference would fail in torch.cat of no chunks)
+        empty = rays_o.new_zeros((0, 3))
+        if return_extras:
+            return empty, rays_o.new_zeros((0, num_samples)), rays_o.new_zeros((0,)), rays_o.new_zeros((0,))
+        return empty
     fused = _fused_model(model)
     if fused:
         model._check_supported()

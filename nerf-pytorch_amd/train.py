@@ -108,7 +108,12 @@ def main(argv=None):
     images, c2w, focal = load_dataset(dataset_path, mode='train')
     images_val, c2w_val, focal_val = load_dataset(dataset_path, mode='val')
     N_val = images.shape[0]  # the reference indexes validation images with the TRAIN count (train.py:115)
-    pool = DeviceRays(images, c2w, focal, device, generator=torch.Generator(device=device).manual_seed(seed))
+    # data-parallel ranks draw the SAME batches (identically seeded generator) and each renders an equal slice:
+    # the short last batch of an epoch is dropped there, so no rank ever gets an empty or unequal slice
+    pool = DeviceRays(images, c2w, focal, device, generator=torch.Generator(device=device).manual_seed(seed),
+                      drop_last=world > 1)
+    if world > 1 and num_random_rays > len(pool):
+        raise ValueError(f"num_random_rays = {num_random_rays} exceeds the {len(pool)} rays of the dataset")
 
     if ckpt is not None:
         model.load_state_dict(ckpt['model_state_dict'])
@@ -118,10 +123,15 @@ def main(argv=None):
         gamma = lr_decay_factor ** (1 / (lr_decay * 1000))
         sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: max(gamma ** s, lr_min / learning_rate))
         flat = None
+        parallel.broadcast_module_parameters(model, 0)
     else:
         flat = parallel.FlatParameters(model)   # one bucket for the network, or for the coarse + fine pair
         flat.broadcast_parameters(0)
         opt = parallel.FusedAdam(flat, lr=learning_rate)
+    # the stratified draw is shared by all rays of a batch (rendering.py:26), hence by all ranks: every rank
+    # draws it from its own generator with the same seed; one broadcast here verifies that they agree
+    ugen = torch.Generator(device=device).manual_seed(seed + 1)
+    parallel.check_shared_draws(device, ugen)
     start_iter = 0
     if ckpt is not None:
         try:
@@ -151,15 +161,17 @@ def main(argv=None):
             o, d, tgt = pool.next_batch(num_random_rays)
             o, d, tgt = o[per_rank], d[per_rank], tgt[per_rank]
             n_chunks = (o.shape[0] + chunk_size - 1) // chunk_size
-            us = [parallel.shared_uniform(num_samples, device) for _ in range(n_chunks)]
+            us = [parallel.shared_uniform(num_samples, device, ugen) for _ in range(n_chunks)]
             preds = render(o, d, us)
             opt.zero_grad()
             loss = sum(mse(p, tgt) for p in preds)
             loss.backward()
             loss = mse(preds[-1].detach(), tgt)   # what is logged: the loss of the image that is kept
             if flat is not None:
-                flat.all_reduce_mean()
+                flat.all_reduce_mean(scale_in_optimizer=True)   # 1/world rides in the Adam kernel's gradient scale
                 opt.lr = learning_rate * parallel.lr_lambda(step, learning_rate, lr_decay, lr_decay_factor, lr_min)
+            else:
+                parallel.all_reduce_module_grads(model)         # torch.optim path: one flattened all-reduce
             opt.step()
             if sched is not None:
                 sched.step()
