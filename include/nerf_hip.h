@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 5
+#define NERF_ABI_VERSION 6
 
 #define NERF_OK 0
 #define NERF_E_ARG (-1)      /* bad shape / size / unsupported configuration */
@@ -75,6 +75,12 @@ int nerf_composite_fwd(const float* colors, const float* densities, const float*
 /* compute_accumulated_transmittance on its own (nerf/rendering.py:110-122): out[r,s] =
  * prod_{j<s} betas[r,j], out[r,0] = 1.  betas, out: [R,S]. */
 int nerf_exclusive_cumprod(const float* betas, int64_t R, int S, float* out, void* stream);
+
+/* What autograd derives for compute_accumulated_transmittance (nerf/rendering.py:120-122: ATen's
+ * cumprod_backward through the shift): grad_out [R,S] = dL/dT -> dbetas [R,S] = dL/dbetas, exact when
+ * betas contain zeros (suffix scan, no division).  1 <= S <= 1024. */
+int nerf_exclusive_cumprod_bwd(const float* betas, const float* grad_out, int64_t R, int S, float* dbetas,
+                               void* stream);
 
 /* Gradient of nerf_composite_fwd's rgb wrt colors and densities (what autograd derives for
  * nerf/rendering.py:143-151, including ATen's zero-safe cumprod backward).

@@ -250,6 +250,59 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void excl_cumprod_kernel(const
         }
 }
 
+// gradient of the exclusive cumulative product: T_s = prod_{k<s} beta_k, g = dL/dT
+//   dL/dbeta_j = T_j * A_j,   A_j = sum_{s>j} g_s prod_{j<k<s} beta_k = g_{j+1} + beta_{j+1} A_{j+1},  A_{S-1} = 0
+// the same zero-safe suffix scan of affine maps as the compositing backward (no division by beta or T),
+// which is what ATen's cumprod_backward yields, shifted by the exclusive offset.
+template <int EPL>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void excl_cumprod_bwd_kernel(const float* __restrict__ betas,
+                                                                              const float* __restrict__ grad_out,
+                                                                              int64_t R, int S,
+                                                                              float* __restrict__ dbetas) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int s0 = lane * EPL;
+    float beta[EPL], g[EPL], Tk[EPL];
+    float prod = 1.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const bool ok = s0 + e < S;
+        beta[e] = ok ? betas[r * S + s0 + e] : 1.0f;     // beyond the ray: identity map
+        g[e] = ok ? grad_out[r * S + s0 + e] : 0.0f;
+        prod *= beta[e];
+    }
+    float T = wave_excl_prod(prod, lane);
+    // F_s(x) = g_s + beta_s x maps A_s to A_{s-1}; this lane's composition C = F_first o ... o F_last
+    float ca = 1.0f, cb = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        Tk[e] = T;
+        T *= beta[e];
+    }
+#pragma unroll
+    for (int e = EPL - 1; e >= 0; --e) {
+        cb = g[e] + beta[e] * cb;
+        ca = beta[e] * ca;
+    }
+    float sa = ca, sb = cb;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float oa = __shfl_down(sa, off), ob = __shfl_down(sb, off);
+        if (lane + off < 64) {
+            sb = sb + sa * ob;
+            sa = sa * oa;
+        }
+    }
+    float x = __shfl_down(sb, 1);   // A at this lane's last sample = S_{l+1}(0)
+    if (lane == 63) x = 0.0f;
+#pragma unroll
+    for (int e = EPL - 1; e >= 0; --e) {
+        if (s0 + e < S) dbetas[r * S + s0 + e] = Tk[e] * x;
+        x = g[e] + beta[e] * x;
+    }
+}
+
 template <int EPL>
 int launch_fwd(const float* colors, const float* dens, const float* deltas, const float* t, int64_t R, int S, int per_ray,
                int white, float* rgb, float* weights, float* depth, float* acc, hipStream_t st) {
@@ -336,4 +389,23 @@ extern "C" int nerf_exclusive_cumprod(const float* betas, int64_t R, int S, floa
     NERF_REQUIRE(ceil_div64(R, kWavesPerBlock) < (1ll << 31), "nerf_exclusive_cumprod: too many rays");
     excl_cumprod_kernel<<<(unsigned)ceil_div64(R, kWavesPerBlock), 64 * kWavesPerBlock, 0, (hipStream_t)stream>>>(betas, R, S, out);
     return nerf_check_launch("nerf_exclusive_cumprod");
+}
+
+extern "C" int nerf_exclusive_cumprod_bwd(const float* betas, const float* grad_out, int64_t R, int S, float* dbetas,
+                                          void* stream) {
+    NERF_REQUIRE(R >= 0 && S >= 1 && S <= 1024, "nerf_exclusive_cumprod_bwd: bad R=%lld S=%d (1..1024)", (long long)R, S);
+    if (R == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(betas);
+    NERF_REQUIRE_PTR(grad_out);
+    NERF_REQUIRE_PTR(dbetas);
+    NERF_REQUIRE(ceil_div64(R, kWavesPerBlock) < (1ll << 31), "nerf_exclusive_cumprod_bwd: too many rays");
+    const unsigned grid = (unsigned)ceil_div64(R, kWavesPerBlock);
+    hipStream_t st = (hipStream_t)stream;
+    const int epl = (S + 63) / 64;
+    if (epl <= 1) excl_cumprod_bwd_kernel<1><<<grid, 64 * kWavesPerBlock, 0, st>>>(betas, grad_out, R, S, dbetas);
+    else if (epl <= 2) excl_cumprod_bwd_kernel<2><<<grid, 64 * kWavesPerBlock, 0, st>>>(betas, grad_out, R, S, dbetas);
+    else if (epl <= 4) excl_cumprod_bwd_kernel<4><<<grid, 64 * kWavesPerBlock, 0, st>>>(betas, grad_out, R, S, dbetas);
+    else if (epl <= 8) excl_cumprod_bwd_kernel<8><<<grid, 64 * kWavesPerBlock, 0, st>>>(betas, grad_out, R, S, dbetas);
+    else excl_cumprod_bwd_kernel<16><<<grid, 64 * kWavesPerBlock, 0, st>>>(betas, grad_out, R, S, dbetas);
+    return nerf_check_launch("nerf_exclusive_cumprod_bwd");
 }

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 MODEL_NERF = 0
 MODEL_SIREN = 1
 NUM_PARAM_TENSORS = 24
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -36,6 +36,7 @@ _SIGS = {
     "nerf_sample_positions": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_double, c_double, _P, _P]),
     "nerf_compute_rays": (c_int, [_P, c_int64, c_int, c_int, c_double, _P, _P, _P]),
     "nerf_exclusive_cumprod": (c_int, [_P, c_int64, c_int, _P, _P]),
+    "nerf_exclusive_cumprod_bwd": (c_int, [_P, _P, c_int64, c_int, _P, _P]),
     "nerf_posenc_fwd": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
     "nerf_composite_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "nerf_composite_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
@@ -170,6 +171,16 @@ def exclusive_cumprod(betas: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(betas)
     _check(lib.nerf_exclusive_cumprod(_dev(betas, "betas"), R, S, _dev(out, "out"), _stream()), "nerf_exclusive_cumprod")
     return out
+
+
+def exclusive_cumprod_bwd(betas: torch.Tensor, grad_out: torch.Tensor) -> torch.Tensor:
+    R, S = betas.shape
+    if grad_out.shape != betas.shape:
+        raise ValueError("exclusive_cumprod_bwd: grad_out must have the shape of betas")
+    dbetas = torch.empty_like(betas)
+    _check(lib.nerf_exclusive_cumprod_bwd(_dev(betas, "betas"), _dev(grad_out, "grad_out"), R, S, _dev(dbetas, "dbetas"),
+                                          _stream()), "nerf_exclusive_cumprod_bwd")
+    return dbetas
 
 
 def posenc(x: torch.Tensor, L: int) -> torch.Tensor:

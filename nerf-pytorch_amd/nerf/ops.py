@@ -200,3 +200,19 @@ class CompositeFunction(torch.autograd.Function):
         colors, densities, deltas = ctx.saved_tensors
         dcolors, ddens = _hip.composite_bwd(colors, densities, deltas, ctx.white, _f32c(grad_rgb))
         return dcolors, ddens, None, None
+
+
+class ExclusiveCumprodFunction(torch.autograd.Function):
+    """T[:, s] = prod_{j<s} betas[:, j] with the gradient autograd derives for the reference's
+    cumprod + shift (rendering.py:120-122), exact for betas that contain zeros."""
+
+    @staticmethod
+    def forward(ctx, betas):
+        betas = _f32c(betas)
+        ctx.save_for_backward(betas)
+        return _hip.exclusive_cumprod(betas)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (betas,) = ctx.saved_tensors
+        return _hip.exclusive_cumprod_bwd(betas, _f32c(grad_out))

@@ -13,7 +13,7 @@ import torch
 from torch import Tensor
 
 from . import _hip
-from .ops import CompositeFunction, RenderFunction, _f32c, grad_sink, wants_grad
+from .ops import CompositeFunction, ExclusiveCumprodFunction, RenderFunction, _f32c, grad_sink, wants_grad
 
 
 def stratified_sampling(near: float, far: float, num_bins: int, device: str = 'cpu', *,
@@ -56,11 +56,14 @@ def query_model(model: torch.nn.Module, sample_positions_flat: Tensor, direction
 
 def compute_accumulated_transmittance(betas: Tensor) -> Tensor:
     """Exclusive cumulative product along dim 1: T[:,0] = 1, T[:,s] = prod_{j<s} betas[:,j]
-    (reference rendering.py:110-122); one ray per wavefront, forward only (inside the renderer
-    the transmittance and its gradient live in the compositing kernels)."""
-    if betas.requires_grad:
-        raise NotImplementedError("use composite_volume for a differentiable transmittance")
-    return _hip.exclusive_cumprod(_f32c(betas))
+    (reference rendering.py:110-122); one ray per wavefront.  Differentiable like the reference's
+    cumprod + shift: the backward is a zero-safe suffix scan (rows of up to 1024 samples).  Inside the
+    renderer the transmittance and its gradient live in the compositing kernels."""
+    if betas.dim() != 2:
+        raise ValueError("compute_accumulated_transmittance expects betas [R,S]")
+    if torch.is_grad_enabled() and betas.requires_grad:
+        return ExclusiveCumprodFunction.apply(betas)
+    return _hip.exclusive_cumprod(_f32c(betas.detach()))
 
 
 def composite_volume(colors: Tensor, densities: Tensor, deltas: Tensor, white_background: bool) -> Tensor:
