@@ -720,12 +720,35 @@ def test_composite_per_ray_depths(hip, S):
     assert rel(dc, c.grad) < RTOL and rel(ds, s.grad) < RTOL
 
 
+def _kink_free_rays(tag, pc, pf, o, d, Nc, Nf, u_c, u_f, margin=3e-6):
+    """Rays none of whose coarse or fine samples has a ReLU pre-activation within `margin` of zero in the
+    oracle (there the ReLU decision, hence a whole gradient path, depends on the matmul's rounding)."""
+    fwd = oracle_fwd(tag)
+    R = o.shape[0]
+    with torch.no_grad():
+        _, _, _, t_all = O.render_hierarchical(lambda x, v: fwd(pc, x, v), lambda x, v: fwd(pf, x, v), o, d, 2.0, 6.0,
+                                               Nc, Nf, u_c, u_f)
+        keep = torch.ones(R, dtype=torch.bool)
+        t_c = O.stratified_t(2.0, 6.0, Nc, u_c)[None].expand(R, -1)
+        for params, t_rays in ((pc, t_c), (pf, t_all)):
+            S = t_rays.shape[1]
+            pos = o[:, None, :] + t_rays[:, :, None] * d[:, None, :]
+            dirs = d[:, None, :].expand(-1, S, -1).reshape(-1, 3)
+            _, _, acts = fwd(params, O.normalize_positions(pos.reshape(-1, 3), 2.0, 6.0), dirs, return_acts=True)
+            keep &= O.relu_kink_distance(acts).reshape(R, S).min(dim=1).values > margin
+    return keep
+
+
 @pytest.mark.parametrize("tag", ["nerf", "siren"])
 def test_hierarchical_render_vs_oracle(tag):
     """Coarse + fine path (no counterpart in the reference: parity unpinned, checked against the
-    canonical-NeRF restatement in the oracle).  The inverse-CDF step is discontinuous in the
-    coarse weights (a last-bit CDF difference can move a sample to the neighbouring bin), so the
-    fine image is compared at 2e-4 relative; the coarse image and its gradients at 1e-5."""
+    canonical-NeRF restatement in the oracle).  Rays with a sample on a ReLU kink are dropped first (as in
+    test_model_ragged_sizes_full_gradients), then the coarse image and EVERY coarse gradient tensor are held
+    to 1e-5.  The fine pass sees depths that went through the inverse-CDF step on the GPU's own coarse weights:
+    a last-bit difference of a depth is multiplied by up to 2^9 in the positional encoding (and a draw within
+    rounding of a CDF value moves a sample to the neighbouring bin), so end to end the fine image is compared at
+    2e-4 and its gradients at 2e-2; fed the ORACLE's depths the fine pass is held to 1e-5 again, image and
+    gradients."""
     from nerf.rendering import render_nerf_hierarchical
     coarse, pc = make_model(tag)
     fine, pf = make_model(tag)
@@ -733,11 +756,15 @@ def test_hierarchical_render_vs_oracle(tag):
         for p in fine.parameters():
             p.mul_(0.97)
         pf = {k: v * 0.97 for k, v in pf.items()}
-    R, Nc, Nf = 96, 64, 128
-    o, d = rays(R, 41)
+    R0, Nc, Nf = 256, 64, 128
+    o, d = rays(R0, 41)
     g = torch.Generator().manual_seed(42)
-    u_c, u_f = torch.rand(Nc, generator=g), torch.rand(R, Nf, generator=g)
-    tgt = torch.rand(R, 3, generator=g)
+    u_c, u_f = torch.rand(Nc, generator=g), torch.rand(R0, Nf, generator=g)
+    tgt = torch.rand(R0, 3, generator=g)
+    keep = _kink_free_rays(tag, pc, pf, o, d, Nc, Nf, u_c, u_f)
+    assert int(keep.sum()) >= 32, int(keep.sum())   # a ray has 256 samples x 2432 ReLU units: about 1 ray in 4 survives
+    o, d, u_f, tgt = o[keep].contiguous(), d[keep].contiguous(), u_f[keep].contiguous(), tgt[keep].contiguous()
+    R = o.shape[0]
     fwd = oracle_fwd(tag)
     for p in list(pc.values()) + list(pf.values()):
         p.requires_grad_(True)
@@ -753,13 +780,9 @@ def test_hierarchical_render_vs_oracle(tag):
     loss = torch.nn.functional.mse_loss(rgb_c, tgt.to(DEV)) + torch.nn.functional.mse_loss(rgb_f, tgt.to(DEV))
     loss.backward()
     n_c = len(pc)
-    # 6144 coarse samples x 2432 ReLU units: a handful of pre-activations sit within rounding of
-    # zero and flip (see test_model_ragged_sizes_full_gradients), hence the looser NeRF bound here;
-    # the sine network has no kinks in its hidden layers
-    ctol = 1e-3 if tag == "nerf" else 3 * RTOL
     for (n, p), gr in zip(coarse.named_parameters(), gc_ref[:n_c]):
-        assert rel(p.grad, gr) < ctol, (n, rel(p.grad, gr))
-    # end to end the fine gradients inherit the bin flips of the re-sampling: sanity bound only
+        assert rel(p.grad, gr) < RTOL, (n, rel(p.grad, gr))
+    # end to end the fine gradients inherit the re-sampling's sensitivity: sanity bound only
     for (n, p), gr in zip(fine.named_parameters(), gc_ref[n_c:]):
         assert rel(p.grad, gr) < 2e-2, (n, rel(p.grad, gr))
     assert float(acc.max()) <= 1 + 1e-5 and float(depth.min()) >= 0
@@ -775,4 +798,42 @@ def test_hierarchical_render_vs_oracle(tag):
     torch.nn.functional.mse_loss(rgb_f2, tgt.to(DEV)).backward()
     gf_ref = torch.autograd.grad(torch.nn.functional.mse_loss(rf, tgt), list(pf.values()))
     for (n, p), gr in zip(fine.named_parameters(), gf_ref):
-        assert rel(p.grad, gr) < ctol, (n, rel(p.grad, gr))
+        assert rel(p.grad, gr) < RTOL, (n, rel(p.grad, gr))
+
+
+@pytest.mark.parametrize("S", [1, 5, 64, 100, 256, 1000])
+def test_accumulated_transmittance_backward_vs_aten(S):
+    """compute_accumulated_transmittance is autograd-transparent in the reference (cumprod + shift,
+    rendering.py:120-122): the drop-in's backward kernel against ATen's cumprod_backward, zeros included."""
+    from nerf.rendering import compute_accumulated_transmittance
+    g = torch.Generator().manual_seed(300 + S)
+    R = 131
+    betas = torch.rand(R, S, generator=g) * 0.6 + 0.4
+    if S >= 5:
+        betas[3, S // 2] = 0.0            # one zero mid-ray
+        betas[4, 1] = 0.0
+        betas[4, S - 2] = 0.0             # two zeros
+        betas[5] = 1.0                    # empty space
+        betas[6, 0] = 0.0
+    gout = torch.randn(R, S, generator=g)
+    ref_in = betas.clone().requires_grad_(True)
+    ref = O.exclusive_transmittance(ref_in)
+    ref.backward(gout)
+    b = betas.to(DEV).requires_grad_(True)
+    T = compute_accumulated_transmittance(b)
+    assert T.requires_grad and rel(T, ref) < 1e-6
+    T.backward(gout.to(DEV))
+    assert torch.isfinite(b.grad).all()
+    assert rel(b.grad, ref_in.grad) < RTOL
+    if S >= 5:
+        for row in (3, 4, 5, 6):
+            assert rel(b.grad[row], ref_in.grad[row]) < RTOL or float(ref_in.grad[row].abs().max()) == 0.0
+    with torch.no_grad():
+        assert not compute_accumulated_transmittance(b).requires_grad
+
+
+def test_render_nerf_no_rays():
+    from nerf.rendering import render_nerf
+    model, _ = make_model("nerf")
+    out = render_nerf(model, torch.zeros(0, 3), torch.zeros(0, 3), 2.0, 6.0, num_samples=16, device=DEV)
+    assert out.shape == (0, 3)
