@@ -175,6 +175,21 @@ int nerf_linear_bwd(const float* dy, int64_t lddy, const float* y, const float* 
                     double post, const float* x, int64_t ldx, const float* W, int64_t M, int K, int N, float* workspace,
                     float* dx, int64_t lddx, float* dW, float* db, void* stream);
 
+/* Allocation-free variant of nerf_linear_bwd.  NO counterpart in the reference: it exists for callers that
+ * cannot allocate device memory around the call -- code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  Same arguments and results as nerf_linear_bwd minus `workspace`: the scratch
+ * (activation gradients, weight-gradient partial slabs, bias partials) is a buffer of
+ * NERF_NOALLOC_SCRATCH_FLOATS floats (32 MiB) built into the library, one copy per GPU, held until the process
+ * ends.  Shapes with nerf_linear_bwd_workspace_floats(M, K, N) > NERF_NOALLOC_SCRATCH_FLOATS are rejected with
+ * NERF_E_ARG.  The call allocates nothing and frees nothing; its first use on a device resolves that device's
+ * buffer address (hipGetSymbolAddress; make that first call outside a graph capture).  All calls on one GPU share the buffer:
+ * calls that overlap on the same GPU (different streams or threads) race; calls on one stream are safe.
+ * The device current at the call must be the one the pointers live on. */
+#define NERF_NOALLOC_SCRATCH_FLOATS (8u << 20)
+int nerf_linear_bwd_noalloc(const float* dy, int64_t lddy, const float* y, const float* aux, int64_t ldy, int act,
+                            double pre, double post, const float* x, int64_t ldx, const float* W, int64_t M, int K, int N,
+                            float* dx, int64_t lddx, float* dW, float* db, void* stream);
+
 /* ---- optimizer: torch.optim.Adam as train.py:123,182 uses it (no weight decay, no amsgrad) --
  * One launch over a flat parameter buffer: p, g, m, v [n].  step is 1-based. */
 int nerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, double lr, double beta1,

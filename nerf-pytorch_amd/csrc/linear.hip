@@ -10,6 +10,15 @@
 #include "common.h"
 #include "sincos.h"
 
+#include <mutex>
+
+// Scratch of nerf_linear_bwd_noalloc: the workspace of nerf_linear_bwd (activation-gradient matrix,
+// weight-gradient partial slabs, bias partials) as a file-scope device array, so that the entry point
+// needs no allocation and no workspace argument.  Every GPU the library runs on holds its own copy at
+// its own address until the process ends.  In host code the NAME `scratch` is only a handle for
+// hipGetSymbolAddress; kernels and memory routines take the per-device address kept in g_scratch_ptr.
+static __device__ __align__(256) float scratch[NERF_NOALLOC_SCRATCH_FLOATS];
+
 namespace {
 
 enum { LIN_NONE = 0, LIN_RELU = 1, LIN_SIN = 2, LIN_SIGMOID = 3 };
@@ -195,12 +204,12 @@ extern "C" int nerf_linear_fwd(const float* x, int64_t ldx, const float* W, cons
     return NERF_OK;
 }
 
-extern "C" int nerf_linear_bwd(const float* dy, int64_t lddy, const float* y, const float* aux, int64_t ldy, int act,
+static int linear_bwd_impl(const char* fn, const float* dy, int64_t lddy, const float* y, const float* aux, int64_t ldy, int act,
                                double pre, double post, const float* x, int64_t ldx, const float* W, int64_t M, int K,
                                int N, float* workspace, float* dx, int64_t lddx, float* dW, float* db, void* stream) {
-    NERF_REQUIRE(M >= 1 && K >= 1 && N >= 1, "nerf_linear_bwd: bad shape M=%lld K=%d N=%d", (long long)M, K, N);
-    NERF_REQUIRE(act >= LIN_NONE && act <= LIN_SIGMOID, "nerf_linear_bwd: unknown activation %d", act);
-    NERF_REQUIRE(ceil_div64(M, BM) <= 65535, "nerf_linear_bwd: more than 65535*64 rows per call");
+    NERF_REQUIRE(M >= 1 && K >= 1 && N >= 1, "%s: bad shape M=%lld K=%d N=%d", fn, (long long)M, K, N);
+    NERF_REQUIRE(act >= LIN_NONE && act <= LIN_SIGMOID, "%s: unknown activation %d", fn, act);
+    NERF_REQUIRE(ceil_div64(M, BM) <= 65535, "%s: more than 65535*64 rows per call", fn);
     NERF_REQUIRE_PTR(dy);
     NERF_REQUIRE_PTR(x);
     NERF_REQUIRE_PTR(W);
@@ -240,4 +249,56 @@ extern "C" int nerf_linear_bwd(const float* dy, int64_t lddy, const float* y, co
         if ((rc = nerf_check_launch("nerf_linear_bwd (bias reduce)"))) return rc;
     }
     return NERF_OK;
+}
+
+extern "C" int nerf_linear_bwd(const float* dy, int64_t lddy, const float* y, const float* aux, int64_t ldy, int act,
+                               double pre, double post, const float* x, int64_t ldx, const float* W, int64_t M, int K,
+                               int N, float* workspace, float* dx, int64_t lddx, float* dW, float* db, void* stream) {
+    return linear_bwd_impl("nerf_linear_bwd", dy, lddy, y, aux, ldy, act, pre, post, x, ldx, W, M, K, N, workspace, dx, lddx,
+                           dW, db, stream);
+}
+
+// ---- the allocation-free variant ----------------------------------------------------------------
+namespace {
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices] = {};   // device address of `scratch` on each GPU, resolved on first use
+std::mutex g_scratch_mutex;
+
+// Address of this device's copy of `scratch` (resolved once per device, with that device current).
+int scratch_for_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return nerf_fail(NERF_E_LAUNCH, "nerf_linear_bwd_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return nerf_fail(NERF_E_ARG, "nerf_linear_bwd_noalloc: device %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        float* ptr = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || ptr == nullptr)
+            return nerf_fail(NERF_E_LAUNCH, "nerf_linear_bwd_noalloc: hipGetSymbolAddress(scratch) on device %d: %s", dev,
+                             hipGetErrorString(e));
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return NERF_OK;
+}
+}  // namespace
+
+extern "C" int nerf_linear_bwd_noalloc(const float* dy, int64_t lddy, const float* y, const float* aux, int64_t ldy,
+                                       int act, double pre, double post, const float* x, int64_t ldx, const float* W,
+                                       int64_t M, int K, int N, float* dx, int64_t lddx, float* dW, float* db,
+                                       void* stream) {
+    NERF_REQUIRE(M >= 1 && K >= 1 && N >= 1, "nerf_linear_bwd_noalloc: bad shape M=%lld K=%d N=%d", (long long)M, K, N);
+    const size_t need = nerf_linear_bwd_workspace_floats(M, K, N);
+    NERF_REQUIRE(need <= (size_t)NERF_NOALLOC_SCRATCH_FLOATS,
+                 "nerf_linear_bwd_noalloc: M=%lld K=%d N=%d needs %zu floats of scratch, the built-in buffer holds %zu "
+                 "(use nerf_linear_bwd with a workspace for larger layers)",
+                 (long long)M, K, N, need, (size_t)NERF_NOALLOC_SCRATCH_FLOATS);
+    float* ws = nullptr;
+    int rc = scratch_for_current_device(&ws);
+    if (rc) return rc;
+    // every scratch element the kernels read is written earlier in the same call (activation gradients,
+    // all Z partial slabs, all Z bias partials), so nothing has to be cleared between calls
+    return linear_bwd_impl("nerf_linear_bwd_noalloc", dy, lddy, y, aux, ldy, act, pre, post, x, ldx, W, M, K, N, ws, dx,
+                           lddx, dW, db, stream);
 }

@@ -53,6 +53,8 @@ _SIGS = {
     "nerf_linear_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_double, c_double, _P, c_int64, _P, _P]),
     "nerf_linear_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_double, c_double, _P, c_int64, _P, c_int64, c_int,
                                 c_int, _P, _P, c_int64, _P, _P, _P]),
+    "nerf_linear_bwd_noalloc": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_double, c_double, _P, c_int64, _P, c_int64,
+                                        c_int, c_int, _P, c_int64, _P, _P, _P]),
     "nerf_merge_samples": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "nerf_mlp_bwd": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "nerf_mlp_bwd_data": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P]),
@@ -344,6 +346,19 @@ def linear_bwd(dy, y, aux, act: int, pre: float, post: float, x, W, need_dx: boo
                                _dev(dW, "dW"), _opt(db, "db"), _stream()), "nerf_linear_bwd")
     timers.stop(ev)
     return dx, dW, db
+
+
+NOALLOC_SCRATCH_FLOATS = 8 << 20
+
+
+def linear_bwd_noalloc(dy, y, aux, act: int, pre: float, post: float, x, W, dx, dW, db) -> None:
+    """nerf_linear_bwd_noalloc: the caller brings every output (dx / db may be None); the library's built-in
+    scratch replaces the workspace, so nothing is allocated between entry and return."""
+    M, K = x.shape
+    N = W.shape[0]
+    _check(lib.nerf_linear_bwd_noalloc(_dev(dy, "dy"), N, _opt(y, "y"), _opt(aux, "aux"), N, act, float(pre), float(post),
+                                       _dev(x, "x"), K, _dev(W, "W"), M, K, N, _opt(dx, "dx"), K, _dev(dW, "dW"),
+                                       _opt(db, "db"), _stream()), "nerf_linear_bwd_noalloc")
 
 
 def adam_step(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0) -> None:
