@@ -37,6 +37,29 @@ static inline int nerf_check_launch(const char* what) {
     return NERF_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel that never changes once
+// set: raise it on the first launch of `kernel` on each device and skip the runtime call afterwards.
+// (A concurrent first call from two threads sets the same value twice, which is harmless.)
+template <typename K>
+static inline int nerf_set_lds(K kernel, int bytes) {
+    constexpr int kSlots = 32, kDevs = 16;
+    static const void* known[kSlots] = {};
+    static unsigned char done[kSlots][kDevs] = {};
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs) dev = -1;
+    int slot = -1;
+    for (int i = 0; i < kSlots; ++i) {
+        if (known[i] == fn) { slot = i; break; }
+        if (known[i] == nullptr) { known[i] = fn; slot = i; break; }
+    }
+    if (slot >= 0 && dev >= 0 && done[slot][dev]) return NERF_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return nerf_fail(NERF_E_LAUNCH, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
+    if (slot >= 0 && dev >= 0) done[slot][dev] = 1;
+    return NERF_OK;
+}
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Individually rounded fp32 operations.  HIP's __fadd_rn/__fmul_rn/... are plain operators

@@ -524,9 +524,7 @@ extern "C" int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const
                , g_bf16_dbg
 #endif
     };
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_fwd_bf16_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, BF16_LDS_BYTES);
-    if (e != hipSuccess) return nerf_fail(NERF_E_LAUNCH, "nerf_mlp_fwd_bf16: LDS attribute: %s", hipGetErrorString(e));
+    if (int rc = nerf_set_lds(nerf_fwd_bf16_kernel, BF16_LDS_BYTES)) return rc;
     nerf_fwd_bf16_kernel<<<(unsigned)groups, WG_THREADS, BF16_LDS_BYTES, (hipStream_t)stream>>>(a);
     return nerf_check_launch("nerf_mlp_fwd_bf16");
 }

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
                 float u = smem[4096];
 #pragma unroll
                 for (int g = 1; g < XGRP; ++g) u += smem[4096 + g];
-                a.qbslab[bid] = u;
+                a.qbslab[(size_t)bid * 4] = u;   // row of 4, three of them unused
             }
         }
     }
@@ -415,121 +415,102 @@ __global__ __launch_bounds__(256) void thin_kernel(ThinArgs a) {
     }
 }
 
-// out[row*s_row + col*s_col] = sum_g slab[g][row][col], row < rows, col < cols_valid
-// acc != 0: the sum is added to what `out` holds (gradient accumulation across calls)
-__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ slab, int G, int rows, int cols,
-                                                     int cols_valid, float* __restrict__ out, int s_row, int s_col, int acc) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * cols) return;
-    const int row = i / cols, col = i - row * cols;
-    if (col >= cols_valid) return;
-    const size_t stride = (size_t)rows * cols;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = 0;
-    for (; g + 4 <= G; g += 4) {
-        s0 += slab[(size_t)g * stride + i];
-        s1 += slab[(size_t)(g + 1) * stride + i];
-        s2 += slab[(size_t)(g + 2) * stride + i];
-        s3 += slab[(size_t)(g + 3) * stride + i];
-    }
-    for (; g < G; ++g) s0 += slab[(size_t)g * stride + i];
-    float* o = out + (size_t)row * s_row + (size_t)col * s_col;
-    *o = (acc ? *o : 0.0f) + ((s0 + s1) + (s2 + s3));
-}
+// ---- one reduction launch for all partial slabs of a network --------------------------------
+// Every weight-gradient launch writes its partials into its own region of the slab area; when all of them
+// are queued, ONE launch adds the G partial slabs of every region into the gradient buffer:
+//     out[row*s_row + col*s_col] (+)= sum_g slab[g][row][col],  row < rows, col < cols_valid.
+// A workgroup owns 64 adjacent float4 of one region; its four 64-lane groups each add every fourth slab
+// (8 independent 16-byte loads in flight), and the groups are combined through LDS -- a fixed order, so
+// the gradients are bitwise reproducible.  rows*cols is a multiple of 4 for every region.
+struct ReduceJob {
+    const float* slab;   // [G][rows*cols]
+    float* out;
+    int G, rows, cols, cols_valid;
+    int s_row, s_col;
+    int block0;          // first workgroup of this job in the launch
+};
+constexpr int kMaxReduceJobs = 32;
+struct ReduceArgs {
+    int njobs, acc;      // acc != 0: add to what `out` holds (gradient accumulation across calls)
+    ReduceJob jobs[kMaxReduceJobs];
+};
 
-// Same sum for slabs whose row length is a multiple of 4 and whose output has unit column stride: a
-// thread owns 4 adjacent outputs (16-byte loads) and every fourth slab, 8 loads in flight; the four
-// slab groups of a workgroup are added through LDS in a fixed order.
-__global__ __launch_bounds__(256) void reduce4_kernel(const float* __restrict__ slab, int G, int rows, int cols,
-                                                      int cols_valid, float* __restrict__ out, int s_row, int acc) {
+__global__ __launch_bounds__(256) void reduce_all_kernel(ReduceArgs a) {
     __shared__ f32x4 part[4][64];
+    int ji = 0;
+    for (int k = 1; k < a.njobs; ++k)
+        if ((int)blockIdx.x >= a.jobs[k].block0) ji = k;     // block0 ascends with the job index
+    const ReduceJob j = a.jobs[ji];
     const int q = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int i4 = blockIdx.x * 64 + q;               // index of this thread's float4 inside one slab
-    const int n4 = rows * cols / 4;
+    const int i4 = ((int)blockIdx.x - j.block0) * 64 + q;    // this thread's float4 inside one slab
+    const int n4 = j.rows * j.cols / 4;
     f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     if (i4 < n4) {
-        const f32x4* base = reinterpret_cast<const f32x4*>(slab) + i4;
+        const f32x4* base = reinterpret_cast<const f32x4*>(j.slab) + i4;
         const size_t stride4 = (size_t)n4;
         int g = grp;
-        for (; g + 28 < G; g += 32) {
+        for (; g + 28 < j.G; g += 32) {
             f32x4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(g + 4 * u) * stride4];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s[u & 1] += v[u];
         }
-        for (; g < G; g += 4) s[0] += base[(size_t)g * stride4];
+        for (; g < j.G; g += 4) s[0] += base[(size_t)g * stride4];
     }
     part[grp][q] = s[0] + s[1];
     __syncthreads();
     if (grp == 0 && i4 < n4) {
         const f32x4 t = (part[0][q] + part[1][q]) + (part[2][q] + part[3][q]);
-        const int row = (4 * i4) / cols, col = 4 * i4 - row * cols;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (col + e < cols_valid) {
-                float* o = out + (size_t)row * s_row + col + e;
-                *o = (acc ? *o : 0.0f) + t[e];
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * i4 + e, row = i / j.cols, col = i - row * j.cols;
+            if (col < j.cols_valid) {
+                float* o = j.out + (size_t)row * j.s_row + (size_t)col * j.s_col;
+                *o = (a.acc ? *o : 0.0f) + t[e];
             }
-    }
-}
-
-// Small outputs (bias vectors, the rank-1 row, the thin products): the sum over slabs is what takes
-// time, so 32 lanes share one output, each adding every 32nd slab (independent loads), and a
-// half-wave butterfly in a fixed order finishes it.
-__global__ __launch_bounds__(256) void reduce_small_kernel(const float* __restrict__ slab, int G, int rows, int cols,
-                                                           int cols_valid, float* __restrict__ out, int s_row, int s_col,
-                                                           int acc) {
-    const int j = threadIdx.x & 31;
-    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int n = rows * cols;
-    float s0 = 0.f, s1 = 0.f;
-    if (i < n) {
-        int g = j;
-        for (; g + 32 < G; g += 64) {
-            s0 += slab[(size_t)g * n + i];
-            s1 += slab[(size_t)(g + 32) * n + i];
-        }
-        if (g < G) s0 += slab[(size_t)g * n + i];
-    }
-    float s = s0 + s1;
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (j == 0 && i < n) {
-        const int row = i / cols, col = i - row * cols;
-        if (col < cols_valid) {
-            float* o = out + (size_t)row * s_row + (size_t)col * s_col;
-            *o = (acc ? *o : 0.0f) + s;
         }
     }
-}
-
-template <typename K>
-int set_lds(K kernel, int bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return nerf_fail(NERF_E_LAUNCH, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
-    return NERF_OK;
 }
 
 struct Ctx {
     hipStream_t st;
     size_t Mp;
-    float* slab;   // SLAB_FLOATS
+    float* slab;      // SLAB_FLOATS: every launch takes the next free region
+    size_t used;
     int rc;
-    int accumulate;   // add to the gradient buffer instead of overwriting it
+    ReduceArgs red;
+    int blocks;
+
+    // region of G slabs of n floats each (n a multiple of 4); NULL (and rc set) when the area is exhausted
+    float* take(int G, int n) {
+        const size_t need = (size_t)G * n;
+        if (rc) return nullptr;
+        if ((n & 3) || used + need > lay::SLAB_FLOATS) {
+            rc = nerf_fail(NERF_E_ARG, "weight gradient: partial-slab area exhausted (%zu + %zu floats)", used, need);
+            return nullptr;
+        }
+        float* p = slab + used;
+        used += need;
+        return p;
+    }
 };
 
 void reduce(Ctx& c, const float* slab, int G, int rows, int cols, int cols_valid, float* out, int s_row, int s_col) {
     if (c.rc) return;
-    if (rows * cols < 4096)
-        reduce_small_kernel<<<(rows * cols + 7) / 8, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, s_col,
-                                                                          c.accumulate);
-    else if (s_col == 1 && cols % 4 == 0)
-        reduce4_kernel<<<(rows * cols / 4 + 63) / 64, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, c.accumulate);
-    else
-        reduce_kernel<<<(rows * cols + 255) / 256, 256, 0, c.st>>>(slab, G, rows, cols, cols_valid, out, s_row, s_col,
-                                                                   c.accumulate);
-    c.rc = nerf_check_launch("wgrad reduce");
+    if (c.red.njobs >= kMaxReduceJobs) {
+        c.rc = nerf_fail(NERF_E_ARG, "weight gradient: more than %d reduction jobs", kMaxReduceJobs);
+        return;
+    }
+    c.red.jobs[c.red.njobs++] = ReduceJob{slab, out, G, rows, cols, cols_valid, s_row, s_col, c.blocks};
+    c.blocks += (rows * cols / 4 + 63) / 64;
+}
+
+int reduce_all(Ctx& c) {
+    if (c.rc) return c.rc;
+    if (c.red.njobs == 0) return NERF_OK;
+    reduce_all_kernel<<<c.blocks, 256, 0, c.st>>>(c.red);
+    return nerf_check_launch("weight gradient reduction");
 }
 
 // dW[:, 0:kvalid] (leading dimension ldw) = dY^T X ; db = column sums of dY (if db).
@@ -540,19 +521,21 @@ void wgrad(Ctx& c, const float* dY, int ldy, const float* X, int ldx, float* dW,
     if (c.rc) return;
     const int nchunks = (int)(c.Mp / 32);
     const int G = nchunks < lay::WG_MAX ? nchunks : lay::WG_MAX;
-    float* bslab = c.slab + (size_t)G * NW * KW;
-    float* qslab = bslab + (size_t)G * NW;
-    float* qbslab = qslab + (size_t)G * KW;
-    WgradArgs a{dY, X, ldy, ldx, nchunks, c.slab, db ? bslab : nullptr, q, qslab, qbslab};
+    float* wslab = c.take(G, NW * KW);
+    float* bslab = db ? c.take(G, NW) : nullptr;
+    float* qslab = RANK1 ? c.take(G, KW) : nullptr;
+    float* qbslab = RANK1 ? c.take(G, 4) : nullptr;   // one value per slab, padded to a 16-byte row
+    if (c.rc) return;
+    WgradArgs a{dY, X, ldy, ldx, nchunks, wslab, bslab, q, qslab, qbslab};
     auto kern = wgrad_kernel<NW, KW, WN, WK, RANK1>;
-    if ((c.rc = set_lds(kern, wgrad_lds_bytes<NW, KW>()))) return;
+    if ((c.rc = nerf_set_lds(kern, wgrad_lds_bytes<NW, KW>()))) return;
     kern<<<G, 512, wgrad_lds_bytes<NW, KW>(), c.st>>>(a);
     if ((c.rc = nerf_check_launch("wgrad"))) return;
-    reduce(c, c.slab, G, NW, KW, kvalid, dW, ldw, 1);
+    reduce(c, wslab, G, NW, KW, kvalid, dW, ldw, 1);
     if (db) reduce(c, bslab, G, 1, NW, NW, db, 0, 1);
     if (RANK1) {
         reduce(c, qslab, G, 1, KW, kvalid, qrow, 0, 1);
-        reduce(c, qbslab, G, 1, 1, 1, qbias, 0, 1);
+        reduce(c, qbslab, G, 1, 4, 1, qbias, 0, 1);
     }
 }
 
@@ -567,12 +550,14 @@ void thin(Ctx& c, const float* P, int ldp, int AW, const float* Q, int NB, float
     }
     int64_t G = (int64_t)c.Mp / 64;
     if (G > 512) G = 512;
-    float* pslab = c.slab + (size_t)G * NB * AW;
-    float* qslab = pslab + (size_t)G * AW;
-    ThinArgs a{P, Q, ldp, AW, NB, (int64_t)c.Mp, c.slab, db_wide ? pslab : nullptr, db_thin ? qslab : nullptr};
+    float* tslab = c.take((int)G, NB * AW);
+    float* pslab = db_wide ? c.take((int)G, AW) : nullptr;
+    float* qslab = db_thin ? c.take((int)G, 4) : nullptr;
+    if (c.rc) return;
+    ThinArgs a{P, Q, ldp, AW, NB, (int64_t)c.Mp, tslab, pslab, qslab};
     thin_kernel<<<(unsigned)G, 256, 0, c.st>>>(a);
     if ((c.rc = nerf_check_launch("thin wgrad"))) return;
-    reduce(c, c.slab, (int)G, NB, AW, AW, out, sb, sa);
+    reduce(c, tslab, (int)G, NB, AW, AW, out, sb, sa);
     if (db_wide) reduce(c, pslab, (int)G, 1, AW, AW, db_wide, 0, 1);
     if (db_thin) reduce(c, qslab, (int)G, 1, 4, NB, db_thin, 0, 1);
 }
@@ -602,10 +587,10 @@ extern "C" int nerf_mlp_bwd_data(int model, const float* packed, int64_t M, cons
     hipStream_t st = (hipStream_t)stream;
     BwdArgs a{packed, M, Mp, dcolors, ddensity, colors, fwd_workspace, bwd_workspace};
     if (model == NERF_MODEL_NERF) {
-        if ((rc = set_lds(nerf_dgrad_kernel, BWD_LDS_BYTES))) return rc;
+        if ((rc = nerf_set_lds(nerf_dgrad_kernel, BWD_LDS_BYTES))) return rc;
         nerf_dgrad_kernel<<<tiles, 256, BWD_LDS_BYTES, st>>>(a);
     } else {
-        if ((rc = set_lds(siren_dgrad_kernel, BWD_LDS_BYTES))) return rc;
+        if ((rc = nerf_set_lds(siren_dgrad_kernel, BWD_LDS_BYTES))) return rc;
         siren_dgrad_kernel<<<tiles, 256, BWD_LDS_BYTES, st>>>(a);
     }
     return nerf_check_launch("nerf_mlp_bwd_data");
@@ -622,7 +607,9 @@ extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_works
     float* bw = bwd_workspace;
     if (model == NERF_MODEL_NERF) {
         using namespace lay::nerf;
-        Ctx c{st, Mp, bw + BW_PER_SAMPLE * Mp, 0, accumulate != 0};
+        Ctx c{st, Mp, bw + BW_PER_SAMPLE * Mp, 0, 0, {}, 0};
+        c.red.njobs = 0;
+        c.red.acc = accumulate != 0;
         auto W = [&](int layer) { return grads + param_off(2 * layer); };
         auto B = [&](int layer) { return grads + param_off(2 * layer + 1); };
         auto h = [&](int l) { return ws + (WS_H + (size_t)l * H) * Mp; };
@@ -640,10 +627,12 @@ extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_works
         wgrad<128, 256, 2, 4>(c, bw + BW_DZ10 * Mp, HH, ws + WS_F * Mp, H, W(10), H + DE, H, B(10));
         wgrad<128, 32, 4, 1>(c, bw + BW_DZ10 * Mp, HH, de, DE_P, W(10) + H, H + DE, DE, nullptr);
         thin(c, ws + WS_G * Mp, HH, HH, bw + BW_DZ11 * Mp, 3, W(11), 1, HH, nullptr, B(11));
-        return c.rc;
+        return reduce_all(c);
     } else {
         using namespace lay::siren;
-        Ctx c{st, Mp, bw + BW_PER_SAMPLE * Mp, 0, accumulate != 0};
+        Ctx c{st, Mp, bw + BW_PER_SAMPLE * Mp, 0, 0, {}, 0};
+        c.red.njobs = 0;
+        c.red.acc = accumulate != 0;
         auto W = [&](int layer) { return grads + param_off(2 * layer); };
         auto B = [&](int layer) { return grads + param_off(2 * layer + 1); };
         auto h = [&](int l) { return ws + (WS_H + (size_t)l * H) * Mp; };
@@ -656,7 +645,7 @@ extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_works
         wgrad<128, 256, 2, 4>(c, bw + BW_DZR * Mp, HH, ws + WS_F * Mp, H, W(10), H + DE, H, B(10));
         wgrad<128, 32, 4, 1>(c, bw + BW_DZR * Mp, HH, ws + WS_DE * Mp, DE_P, W(10) + H, H + DE, DE, nullptr);
         thin(c, ws + WS_G * Mp, HH, HH, bw + BW_DZO * Mp, 3, W(11), 1, HH, nullptr, B(11));
-        return c.rc;
+        return reduce_all(c);
     }
 }
 

@@ -491,13 +491,6 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
     if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
 }
 
-template <typename K>
-int set_lds(K kernel, int bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return nerf_fail(NERF_E_LAUNCH, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
-    return NERF_OK;
-}
-
 #ifdef NERF_DIAG
 unsigned long long* g_fwd_dbg = nullptr;
 #endif
@@ -537,18 +530,18 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
     int rc;
     if (model == NERF_MODEL_NERF) {
         if (workspace) {
-            if ((rc = set_lds(nerf_fwd_kernel<true>, FWD_LDS_BYTES))) return rc;
+            if ((rc = nerf_set_lds(nerf_fwd_kernel<true>, FWD_LDS_BYTES))) return rc;
             nerf_fwd_kernel<true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
         } else {
-            if ((rc = set_lds(nerf_fwd_kernel<false>, FWD_LDS_BYTES))) return rc;
+            if ((rc = nerf_set_lds(nerf_fwd_kernel<false>, FWD_LDS_BYTES))) return rc;
             nerf_fwd_kernel<false><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
         }
     } else {
         if (workspace) {
-            if ((rc = set_lds(siren_fwd_kernel<true>, FWD_LDS_BYTES))) return rc;
+            if ((rc = nerf_set_lds(siren_fwd_kernel<true>, FWD_LDS_BYTES))) return rc;
             siren_fwd_kernel<true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
         } else {
-            if ((rc = set_lds(siren_fwd_kernel<false>, FWD_LDS_BYTES))) return rc;
+            if ((rc = nerf_set_lds(siren_fwd_kernel<false>, FWD_LDS_BYTES))) return rc;
             siren_fwd_kernel<false><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
         }
     }

@@ -114,10 +114,13 @@ constexpr size_t BW_DZ = 0, BW_DZF = 8 * H, BW_DZR = BW_DZF + H, BW_DZO = BW_DZR
 constexpr size_t BW_PER_SAMPLE = BW_DSIG + 1;
 }  // namespace siren
 
-// wgrad partial slabs shared by both models: WG_MAX workgroups x (256*256 weight partials + 256 bias
-// partials + 256 + 4 partials of the rank-1 density row and its bias) floats
+// Weight-gradient partial slabs.  Every per-layer launch owns a region [G][outputs] of the slab area (G <=
+// WG_MAX workgroups for the MFMA launches, <= 512 for the thin VALU products), so that ONE reduction launch
+// can add all of them at the end.  Per G the MFMA launches of the larger network (NeRF) write
+// 2*(256*64) + 9*(256*256) + 128*256 + 128*32 weight partials and 10*256 + 128 + 256 + 4 bias / rank-1
+// partials = 662,404 floats; the thin products at most 3*256 + 256 + 4 floats.
 constexpr int WG_MAX = 256;
-constexpr size_t SLAB_FLOATS = (size_t)WG_MAX * ((size_t)H * H + 2 * H + 4);
+constexpr size_t SLAB_FLOATS = (size_t)WG_MAX * 664000 + (size_t)512 * 2048;
 
 inline size_t padded_samples(long long M) { return (size_t)((M + TILE - 1) / TILE) * TILE; }
 
