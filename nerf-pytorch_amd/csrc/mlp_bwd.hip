@@ -22,7 +22,7 @@ struct BwdArgs {
     float* bw;
 };
 
-constexpr int BWD_LDS_BYTES = (ACT_FLOATS + lay::TILE) * 4;
+constexpr int BWD_LDS_BYTES = (ACT_FLOATS + TR) * 4;
 
 // Tile prologue shared by both models: gradient of the 128 -> 3 sigmoid head.
 //   dzo[c] = dcolors * c * (1 - c) * out_scale      -> bw_dzo [Mp][4]
@@ -34,7 +34,7 @@ __device__ __forceinline__ void head_bwd(const BwdArgs& a, size_t m0, float* act
                                          const float* __restrict__ wout, const float* __restrict__ gsrc,
                                          const float* __restrict__ sraw, float dens_scale, float* __restrict__ bw_dzo,
                                          float* __restrict__ bw_dsig, float* __restrict__ bw_dzr, int tid) {
-    const int smp = tid >> 2, q = tid & 3;
+    const int smp = tid / TPS, q = tid % TPS;
     const size_t m = m0 + smp;
     float dz[3] = {0.f, 0.f, 0.f};
     float ds = 0.f;
@@ -53,8 +53,8 @@ __device__ __forceinline__ void head_bwd(const BwdArgs& a, size_t m0, float* act
         dsig_s[smp] = ds;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = 4 * (4 * i + q);
+    for (int i = 0; i < 32 / TPS; ++i) {
+        const int k = 4 * (TPS * i + q);
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wout + k);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(wout + lay::HH + k);
         const f32x4 w2 = *reinterpret_cast<const f32x4*>(wout + 2 * lay::HH + k);
@@ -77,11 +77,11 @@ template <int MASK, bool RANK1, int COPY_COLS>
 __device__ __forceinline__ void dgrad_layer(float* act, const float* __restrict__ timg, int kb_count, int ncol0,
                                             int tid, const float* hsrc, float* gin, const float* dsig_s,
                                             const float* __restrict__ sigw,
-                                            const unsigned long long* __restrict__ mask_word = nullptr) {
+                                            const mask_t* __restrict__ mask_word = nullptr) {
     const int lane = tid & 63;
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
     init_bias<2>(acc, nullptr, ncol0, lane);
-    unsigned long long bits = 0ull;
+    mask_t bits = 0;
     if constexpr (MASK == 3) bits = *mask_word;  // one 8-byte load, in flight during the whole K loop
     mma_layer<2, COPY_COLS>(act, timg, lay::H, kb_count, ncol0, lane, acc, gin, tid);
     __syncthreads();
@@ -89,7 +89,7 @@ __device__ __forceinline__ void dgrad_layer(float* act, const float* __restrict_
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 2) void nerf_dgrad_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, WG_PER_CU) void nerf_dgrad_kernel(BwdArgs a) {
     using namespace lay;
     using namespace lay::nerf;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void nerf_dgrad_kernel(BwdArgs a) {
     float* dsig_s = smem + ACT_FLOATS;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t m0 = (size_t)blockIdx.x * TILE;
+    const size_t m0 = (size_t)blockIdx.x * TR;
     const size_t Mp = a.Mp;
     const float* __restrict__ pk = a.pk;
     const float* ws = a.ws;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void nerf_dgrad_kernel(BwdArgs a) {
     // rgb_head.0 (feature part): reduce over its 128 outputs -> gradient of the 256 features (dz9)
     dgrad_layer<0, false, 0>(act, pk + D10, HH / 8, ncol0, tid, nullptr, nullptr, nullptr, nullptr);
     auto mskp = [&](int l) {
-        return reinterpret_cast<const unsigned long long*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid;
+        return reinterpret_cast<const mask_t*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid;
     };
     // block2.8: 256 feature rows on MFMA + the density row as a rank-1 term, ReLU mask of h8 -> dz8
     dgrad_layer<3, true, H>(act, pk + d_img(9), H / 8, ncol0, tid, nullptr, bw + BW_DZ9 * Mp + m0 * H, dsig_s, pk + SIGW,
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void nerf_dgrad_kernel(BwdArgs a) {
     store_tile(act, H, dzp(0), H, tid);
 }
 
-__global__ __launch_bounds__(256, 2) void siren_dgrad_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, WG_PER_CU) void siren_dgrad_kernel(BwdArgs a) {
     using namespace lay;
     using namespace lay::siren;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void siren_dgrad_kernel(BwdArgs a) {
     float* dsig_s = smem + ACT_FLOATS;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t m0 = (size_t)blockIdx.x * TILE;
+    const size_t m0 = (size_t)blockIdx.x * TR;
     const size_t Mp = a.Mp;
     const float* __restrict__ pk = a.pk;
     const float* ws = a.ws;
@@ -570,7 +570,7 @@ static int bwd_check_args(const char* fn, int model, const float* packed, int64_
     NERF_REQUIRE(M >= 1, "%s: M=%lld < 1", fn, (long long)M);
     if (!packed || !fwd_workspace || !bwd_workspace) return nerf_fail(NERF_E_NULL, "%s: NULL pointer argument", fn);
     const size_t Mp = lay::padded_samples(M);
-    NERF_REQUIRE(Mp / lay::TILE < (1ull << 31), "%s: too many samples", fn);
+    NERF_REQUIRE(Mp / TR < (1ull << 31), "%s: too many samples", fn);
     return NERF_OK;
 }
 
@@ -583,7 +583,7 @@ extern "C" int nerf_mlp_bwd_data(int model, const float* packed, int64_t M, cons
     NERF_REQUIRE_PTR(ddensity);
     NERF_REQUIRE_PTR(colors);
     const size_t Mp = padded_samples(M);
-    const unsigned tiles = (unsigned)(Mp / TILE);
+    const unsigned tiles = (unsigned)(Mp / TR);
     hipStream_t st = (hipStream_t)stream;
     BwdArgs a{packed, M, Mp, dcolors, ddensity, colors, fwd_workspace, bwd_workspace};
     if (model == NERF_MODEL_NERF) {

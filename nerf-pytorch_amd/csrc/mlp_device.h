@@ -1,10 +1,10 @@
 // Device building blocks of the fused MLP kernels (gfx950, wave64, fp32 MFMA).
 //
-// Tile geometry: a workgroup of 4 waves owns 64 samples.  The current layer input
-// lives in LDS as act[64][LDA] (row = sample, LDA = 260 floats so that the 16-byte A
-// fragment reads of 32 consecutive rows fall on distinct banks).  Wave w computes all
-// 64 rows x columns [w*32*NT, (w+1)*32*NT) of the layer output with
-// v_mfma_f32_32x32x2_f32: acc[mi][ni] is the 32x32 tile (rows 32*mi.., cols ncol0+32*ni..).
+// Tile geometry: a workgroup of 4 waves owns TR samples (NERF_TILE_ROWS: 64, two workgroups per CU,
+// or 32, four per CU).  The current layer input lives in LDS as act[TR][LDA] (row = sample, LDA = 260
+// floats so that the 16-byte A fragment reads of 32 consecutive rows fall on distinct banks).  Wave w
+// computes all TR rows x columns [w*32*NT, (w+1)*32*NT) of the layer output with
+// v_mfma_f32_32x32x2_f32: acc[mi][ni] is the 32x32 tile (rows 32*mi.., cols ncol0+32*ni..), mi < MT = TR/32.
 //
 // MFMA operand maps (32x32x2 f32): lane l supplies A[row l&31][k l>>5] and
 // B[k l>>5][col l&31]; accumulator register g of lane l is
@@ -17,10 +17,23 @@
 #include "mlp_layout.h"
 #include "sincos.h"
 
+#include <type_traits>
+
 namespace dev {
 
+#ifndef NERF_TILE_ROWS
+#define NERF_TILE_ROWS 64
+#endif
+constexpr int TR = NERF_TILE_ROWS;          // samples per workgroup tile
+constexpr int MT = TR / 32;                 // 32-row MFMA tiles per wave
+constexpr int TPS = 256 / TR;               // threads per sample in the per-sample phases (encodings, heads)
+constexpr int WG_PER_CU = TR == 64 ? 2 : 4; // LDS and register budget of the tile kernels
+static_assert((TR == 32 || TR == 64) && lay::TILE % TR == 0, "tile height");
+// (h > 0) bits of one lane's accumulators of a 256-wide layer: MT*2 tiles x 16 registers
+typedef std::conditional<MT == 2, unsigned long long, unsigned>::type mask_t;
+
 constexpr int LDA = 260;
-constexpr int ACT_FLOATS = lay::TILE * LDA;
+constexpr int ACT_FLOATS = TR * LDA;
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIN = 2 };
 
@@ -33,13 +46,13 @@ __device__ __forceinline__ f32x16 splat16(float v) {
     return r;
 }
 
-// One K block of MFMAs for the wave's 64 x (32*NT) tile: 4 steps x 2 x NT instructions.
+// One K block of MFMAs for the wave's TR x (32*NT) tile: 4 steps x MT x NT instructions.
 template <int NT>
-__device__ __forceinline__ void mma_block(const f32x4 (&a)[2], const f32x4 (&b)[NT], f32x16 (&acc)[2][NT]) {
+__device__ __forceinline__ void mma_block(const f32x4 (&a)[MT], const f32x4 (&b)[NT], f32x16 (&acc)[MT][NT]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
@@ -59,9 +72,9 @@ __device__ __forceinline__ void load_b(__amdgpu_buffer_rsrc_t img, int voff, int
     for (int ni = 0; ni < NT; ++ni)
         b[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(img, voff + ni * 1024, kb * kb_bytes, 0));
 }
-__device__ __forceinline__ void load_a(const float* a_ptr, int kb, f32x4 (&a)[2]) {
+__device__ __forceinline__ void load_a(const float* a_ptr, int kb, f32x4 (&a)[MT]) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a_ptr + mi * 32 * LDA + kb * 8);
+    for (int mi = 0; mi < MT; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a_ptr + mi * 32 * LDA + kb * 8);
 }
 
 // acc[mi][ni] (+)= act[rows 32*mi.., k < 8*kb_count] * img, img = packed image with `n_img`
@@ -73,15 +86,15 @@ __device__ __forceinline__ void load_a(const float* a_ptr, int kb, f32x4 (&a)[2]
 // fetch on every block.  (A three-block-deep ring was measured and is not faster.)  The loop is
 // deliberately not unrolled further: twelve fully unrolled layers are ~90 KB of code.
 //
-// COPY_COLS != 0 (= 8*kb_count): the loop also copies the tile it reads, act[64][COPY_COLS], to
-// global rows of COPY_COLS floats at gcopy -- one 16-byte piece per thread and loop iteration
-// (64*COPY_COLS/4 pieces = 256 threads * kb_count/2 iterations).  The piece is read from LDS one
-// iteration ahead and stored right after the weight loads of the odd block: vmcnt retires in
-// order, so the first wait that covers the store is the one for the weight loads issued a whole
-// MFMA block later, and no wave ever sits on a store acknowledgement.
+// COPY_COLS != 0 (= 8*kb_count): the loop also copies the tile it reads, act[TR][COPY_COLS], to
+// global rows of COPY_COLS floats at gcopy -- one 16-byte piece per thread and storing iteration
+// (TR*COPY_COLS/4 pieces = 256 threads * kb_count/2 iterations for 64 rows; with 32 rows every second
+// iteration stores).  The piece is read from LDS one iteration ahead and stored right after the weight
+// loads of the odd block: vmcnt retires in order, so the first wait that covers the store is the one
+// for the weight loads issued a whole MFMA block later, and no wave ever sits on a store acknowledgement.
 template <int NT, int COPY_COLS = 0>
 __device__ __forceinline__ void mma_layer(const float* act, const float* __restrict__ img, int n_img, int kb_count,
-                                          int ncol0, int lane, f32x16 (&acc)[2][NT], float* __restrict__ gcopy = nullptr,
+                                          int ncol0, int lane, f32x16 (&acc)[MT][NT], float* __restrict__ gcopy = nullptr,
                                           int tid = 0) {
     const int r = lane & 31, h = lane >> 5;
     const float* a_ptr = act + r * LDA + 4 * h;
@@ -89,9 +102,10 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
     const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(img, (unsigned)(kb_count * kb_bytes));
     const int b_voff = ((ncol0 + r) * 8 + 4 * h) * 4;
     const int last = kb_count - 1;
-    f32x4 a0[2], a1[2], b0[NT], b1[NT];
+    f32x4 a0[MT], a1[MT], b0[NT], b1[NT];
     constexpr int C4N = COPY_COLS ? COPY_COLS / 4 : 1;       // 16-byte pieces per tile row
-    constexpr int RSTEP = 256 / C4N;                         // tile rows covered per iteration
+    constexpr int RSTEP = 256 / C4N;                         // tile rows covered per storing iteration
+    constexpr int SE = 64 / TR;                              // every SE-th iteration stores
     const float* csrc = nullptr;
     __amdgpu_buffer_rsrc_t c_rsrc = b_rsrc;
     int c_voff = 0, c_soff = 0;
@@ -99,7 +113,7 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
     if constexpr (COPY_COLS != 0) {
         const int row = tid / C4N, c4 = tid % C4N;
         csrc = act + row * LDA + 4 * c4;
-        c_rsrc = make_rsrc(gcopy, lay::TILE * COPY_COLS * 4);
+        c_rsrc = make_rsrc(gcopy, TR * COPY_COLS * 4);
         c_voff = (row * COPY_COLS + 4 * c4) * 4;
         piece = *reinterpret_cast<const f32x4*>(csrc);
     }
@@ -109,13 +123,16 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
     for (int kb = 0; kb < kb_count; kb += 2) {
         load_b<NT>(b_rsrc, b_voff, kb + 1, kb_bytes, b1);
         if constexpr (COPY_COLS != 0) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, piece), c_rsrc, c_voff, c_soff, 2);  // 2 = nt
-            c_soff += RSTEP * COPY_COLS * 4;
+            if (SE == 1 || ((kb >> 1) & (SE - 1)) == 0) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, piece), c_rsrc, c_voff, c_soff, 2);  // 2 = nt
+                c_soff += RSTEP * COPY_COLS * 4;
+                csrc += RSTEP * LDA;
+            }
         }
         load_a(a_ptr, kb + 1, a1);
         if constexpr (COPY_COLS != 0) {
-            csrc += RSTEP * LDA;
-            if (kb + 2 < kb_count) piece = *reinterpret_cast<const f32x4*>(csrc);
+            if ((SE == 1 || (((kb >> 1) + 1) & (SE - 1)) == 0) && kb + 2 < kb_count)
+                piece = *reinterpret_cast<const f32x4*>(csrc);
         }
         __builtin_amdgcn_sched_barrier(0);
         mma_block<NT>(a0, b0, acc);
@@ -131,12 +148,12 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
 
 // accumulators start at the bias of their column
 template <int NT>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[2][NT], const float* __restrict__ bias, int ncol0, int lane) {
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[MT][NT], const float* __restrict__ bias, int ncol0, int lane) {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
         const float b = bias ? bias[ncol0 + 32 * ni + (lane & 31)] : 0.0f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = splat16(b);
+        for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = splat16(b);
     }
 }
 
@@ -145,22 +162,22 @@ __device__ __forceinline__ int acc_row(int mi, int g, int lane) { return 32 * mi
 // Forward epilogue: activation, write the tile back to LDS as the next layer's input.
 // The post-activation tile itself goes to the workspace later, from LDS, inside the next MFMA loop
 // that reads it (mma_layer's COPY_COLS); for sine layers (training) the derivative cos(z) has no LDS
-// home and is stored from the accumulator layout: gcos = row 0 of this tile, [64][ldg].
-// relu_mask (may be NULL): receives this lane's 64 (v > 0) bits, accumulator order.
+// home and is stored from the accumulator layout: gcos = row 0 of this tile, [TR][ldg].
+// relu_mask (may be NULL): receives this lane's MT*32 (v > 0) bits, accumulator order.
 template <int NT, int ACT, bool STORE_COS>
-__device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], int ncol0, int lane,
+__device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], int ncol0, int lane,
                                              float* __restrict__ gcos, int ldg,
-                                             unsigned long long* __restrict__ relu_mask = nullptr) {
+                                             mask_t* __restrict__ relu_mask = nullptr) {
     unsigned mlo = 0u, mhi = 0u;
     // derivative tile: buffer stores (one resource, one lane offset, the element in the constant offset)
     __amdgpu_buffer_rsrc_t cos_rsrc;
     int cos_voff = 0;
     if constexpr (STORE_COS && ACT == ACT_SIN) {
-        cos_rsrc = make_rsrc(gcos, (unsigned)(lay::TILE * ldg * 4));
+        cos_rsrc = make_rsrc(gcos, (unsigned)(TR * ldg * 4));
         cos_voff = (4 * (lane >> 5) * ldg + ncol0 + (lane & 31)) * 4;
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int col = ncol0 + 32 * ni + (lane & 31);
@@ -172,8 +189,6 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                 if constexpr (ACT == ACT_RELU) {
                     v = fmaxf(v, 0.0f);
                     if constexpr (NT == 2) {
-                        constexpr unsigned dummy = 0;
-                        (void)dummy;
                         const int bit = (mi * NT + ni) * 16 + g;
                         if (bit < 32) mlo |= (v > 0.0f) ? (1u << (bit & 31)) : 0u;
                         else mhi |= (v > 0.0f) ? (1u << (bit & 31)) : 0u;
@@ -191,7 +206,10 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
             }
         }
     if constexpr (ACT == ACT_RELU && NT == 2) {
-        if (relu_mask) *relu_mask = ((unsigned long long)mhi << 32) | mlo;
+        if (relu_mask) {
+            if constexpr (MT == 2) *relu_mask = ((unsigned long long)mhi << 32) | mlo;
+            else *relu_mask = mlo;
+        }
     }
 }
 
@@ -203,15 +221,15 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
 //   MASK 3: derivative = bit of `bits`      (ReLU; the forward's per-lane mask word)
 //   MASK 0: none
 template <int NT, int MASK, bool RANK1>
-__device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], int ncol0, int lane,
+__device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[MT][NT], int ncol0, int lane,
                                              const float* __restrict__ hsrc, int ldg,
                                              const float* dsig_lds, const float* __restrict__ sigw,
-                                             unsigned long long bits = 0ull) {
-    const unsigned blo = (unsigned)bits, bhi = (unsigned)(bits >> 32);
+                                             mask_t bits = 0) {
+    const unsigned blo = (unsigned)bits, bhi = (unsigned)((unsigned long long)bits >> 32);
     __amdgpu_buffer_rsrc_t h_rsrc;
     int h_voff = 0;
     if constexpr (MASK == 1 || MASK == 2) {
-        h_rsrc = make_rsrc(hsrc, (unsigned)(lay::TILE * ldg * 4));
+        h_rsrc = make_rsrc(hsrc, (unsigned)(TR * ldg * 4));
         h_voff = (4 * (lane >> 5) * ldg + ncol0 + (lane & 31)) * 4;
     }
     auto stored = [&](int mi, int ni, int g) {
@@ -219,7 +237,7 @@ __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
                                              h_rsrc, h_voff, ((32 * mi + (g & 3) + 8 * (g >> 2)) * ldg + 32 * ni) * 4, 0));
     };
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int col = ncol0 + 32 * ni + (lane & 31);
@@ -241,14 +259,14 @@ __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[2][NT], i
         }
 }
 
-// positional encoding of one coordinate into a tile row: writes x and L sin/cos pairs.
-// `dst` points at the row start; column layout of nerf/encoding.py (blocks of 3).
-template <int L>
-__device__ __forceinline__ void encode_axis(float* dst, int axis, float x) {
-    dst[axis] = x;
-    float scale = 1.0f;
+// positional encoding of one coordinate into a tile row: frequencies j0 <= j < j1 of the sin/cos
+// pairs, plus x itself when j0 == 0.  `dst` points at the row start; column layout of nerf/encoding.py
+// (blocks of 3).
+__device__ __forceinline__ void encode_axis(float* dst, int axis, float x, int j0, int j1) {
+    if (j0 == 0) dst[axis] = x;
+    float scale = (float)(1 << j0);
 #pragma unroll 1   // one copy of the full-range sincos (its large-argument path is ~100 instructions)
-    for (int j = 0; j < L; ++j) {
+    for (int j = j0; j < j1; ++j) {
         float s, c;
         nerf_sincosf(mul_rn(scale, x), &s, &c);
         dst[3 + 6 * j + axis] = s;
@@ -259,10 +277,10 @@ __device__ __forceinline__ void encode_axis(float* dst, int axis, float x) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// copy `cols` (multiple of 4) columns of the 64-row LDS tile to global rows of `ldg` floats
+// copy `cols` (multiple of 4) columns of the TR-row LDS tile to global rows of `ldg` floats
 __device__ __forceinline__ void store_tile(const float* act, int cols, float* __restrict__ g, int ldg, int tid) {
     const int c4n = cols >> 2;
-    for (int i = tid; i < lay::TILE * c4n; i += 256) {
+    for (int i = tid; i < TR * c4n; i += 256) {
         const int row = i / c4n, c4 = i - row * c4n;
         *reinterpret_cast<f32x4*>(g + (size_t)row * ldg + 4 * c4) = *reinterpret_cast<const f32x4*>(act + row * LDA + 4 * c4);
     }

@@ -171,8 +171,8 @@ struct FwdArgs {
 #define DIAG_STAMP(i) ((void)0)
 #endif
 
-constexpr int XIN_FLOATS = lay::TILE * 8;
-constexpr int FWD_LDS_BYTES = (ACT_FLOATS + XIN_FLOATS + lay::TILE) * 4;
+constexpr int XIN_FLOATS = TR * 8;
+constexpr int FWD_LDS_BYTES = (ACT_FLOATS + XIN_FLOATS + TR) * 4;
 
 __device__ __forceinline__ float norm_coord(float p, float nearf, float spanf) {
 #pragma clang fp contract(off)  // each operation rounded on its own, as the reference's tensor ops are
@@ -182,7 +182,7 @@ __device__ __forceinline__ float norm_coord(float p, float nearf, float spanf) {
 // xin[s][0..2] = normalised position, xin[s][3..5] = direction (zeros beyond M)
 __device__ __forceinline__ void load_inputs(const FwdArgs& a, size_t m0, float* xin, int tid) {
 #pragma clang fp contract(off)  // o + t*d must not become an FMA (bit-exact positions)
-    if (tid < lay::TILE) {
+    if (tid < TR) {
         const size_t m = m0 + tid;
         float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
         if (m < (size_t)a.M) {
@@ -204,45 +204,53 @@ __device__ __forceinline__ void load_inputs(const FwdArgs& a, size_t m0, float* 
     }
 }
 
+// TPS threads per sample: one per axis (64-row tiles), or two per axis that split the frequencies
+// (32-row tiles); the next thread zeroes the padding columns
+constexpr int ENC_SPLIT = TPS / 4;   // 1 or 2 threads per axis
 __device__ __forceinline__ void encode_pe(float* act, const float* xin, int tid) {
-    const int smp = tid >> 2, q = tid & 3;
-    if (q < 3) encode_axis<10>(act + smp * LDA, q, xin[smp * 8 + q]);
-    else act[smp * LDA + 63] = 0.0f;
+    const int smp = tid / TPS, q = tid % TPS;
+    if (q < 3 * ENC_SPLIT) {
+        const int axis = q % 3, part = q / 3;
+        encode_axis(act + smp * LDA, axis, xin[smp * 8 + axis], part * (10 / ENC_SPLIT), (part + 1) * (10 / ENC_SPLIT));
+    } else if (q == 3 * ENC_SPLIT) act[smp * LDA + 63] = 0.0f;
 }
 __device__ __forceinline__ void encode_de(float* act, const float* xin, int tid) {
-    const int smp = tid >> 2, q = tid & 3;
-    if (q < 3) encode_axis<4>(act + smp * LDA, q, xin[smp * 8 + 3 + q]);
-    else {
+    const int smp = tid / TPS, q = tid % TPS;
+    if (q < 3 * ENC_SPLIT) {
+        const int axis = q % 3, part = q / 3;
+        encode_axis(act + smp * LDA, axis, xin[smp * 8 + 3 + axis], part * (4 / ENC_SPLIT), (part + 1) * (4 / ENC_SPLIT));
+    } else if (q == 3 * ENC_SPLIT) {
 #pragma unroll
         for (int c = lay::DE; c < lay::DE_P; ++c) act[smp * LDA + c] = 0.0f;
     }
 }
 
-// dot of each tile row (first 256 columns) with a 256-vector; 4 threads per sample
+// dot of each tile row (first 256 columns) with a 256-vector; TPS threads per sample
 __device__ __forceinline__ float row_dot256(const float* act, const float* __restrict__ w, int tid) {
-    const int smp = tid >> 2, q = tid & 3;
+    const int smp = tid / TPS, q = tid % TPS;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int k = 4 * (4 * i + q);
+    for (int i = 0; i < 64 / TPS; ++i) {
+        const int k = 4 * (TPS * i + q);
         const f32x4 hv = *reinterpret_cast<const f32x4*>(act + smp * LDA + k);
         const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
         s += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
     }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
+    if constexpr (TPS == 8) s += __shfl_xor(s, 4);
     return s;
 }
 
-// 128 -> 3 output layer + sigmoid; 4 threads per sample over act[:, 0:128]
+// 128 -> 3 output layer + sigmoid; TPS threads per sample over act[:, 0:128]
 __device__ __forceinline__ void head_out(const float* act, const float* __restrict__ w, const float* __restrict__ b,
                                          float rgb_mul, float dens, size_t m0, int64_t M, float* __restrict__ colors,
                                          float* __restrict__ density, int tid) {
-    const int smp = tid >> 2, q = tid & 3;
+    const int smp = tid / TPS, q = tid % TPS;
     float z[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = 4 * (4 * i + q);
+    for (int i = 0; i < 32 / TPS; ++i) {
+        const int k = 4 * (TPS * i + q);
         const f32x4 gv = *reinterpret_cast<const f32x4*>(act + smp * LDA + k);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -254,6 +262,7 @@ __device__ __forceinline__ void head_out(const float* act, const float* __restri
     for (int c = 0; c < 3; ++c) {
         z[c] += __shfl_xor(z[c], 1);
         z[c] += __shfl_xor(z[c], 2);
+        if constexpr (TPS == 8) z[c] += __shfl_xor(z[c], 4);
     }
     const size_t m = m0 + smp;
     if (q == 0 && m < (size_t)M) {
@@ -271,10 +280,10 @@ __device__ __forceinline__ void head_out(const float* act, const float* __restri
 template <int ACT, bool TRAIN, int IN_COLS>
 __device__ __forceinline__ void hidden_layer(float* act, const float* __restrict__ img,
                                              const float* __restrict__ bias, int ncol0, int tid, float* gin,
-                                             float* gcos, unsigned long long* gmask_in = nullptr,
-                                             unsigned long long* mask = nullptr, unsigned long long* stamps = nullptr) {
+                                             float* gcos, mask_t* gmask_in = nullptr,
+                                             mask_t* mask = nullptr, unsigned long long* stamps = nullptr) {
     const int lane = tid & 63;
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #ifdef NERF_DIAG
 #define LAYER_STAMP(i)                                                         \
     do {                                                                       \
@@ -301,7 +310,7 @@ __device__ __forceinline__ void hidden_layer(float* act, const float* __restrict
 }
 
 template <bool TRAIN>
-__global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
     using namespace lay;
     using namespace lay::nerf;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -310,14 +319,14 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
     float* sraw_s = xin + XIN_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t m0 = (size_t)blockIdx.x * TILE;
+    const size_t m0 = (size_t)blockIdx.x * TR;
     const float* __restrict__ pk = a.pk;
     float* ws = a.ws;
     const size_t Mp = a.Mp;
     auto wsp = [&](size_t off, int width) -> float* { return TRAIN ? ws + off * Mp + m0 * width : nullptr; };
     // this lane's ReLU mask word of layer l (training only)
-    auto mskp = [&](int l) -> unsigned long long* {
-        return TRAIN ? reinterpret_cast<unsigned long long*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid : nullptr;
+    auto mskp = [&](int l) -> mask_t* {
+        return TRAIN ? reinterpret_cast<mask_t*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid : nullptr;
     };
 
 #ifdef NERF_DIAG
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
 
     const int ncol0 = wave * 64;
     // L0: K 64 (input tile = the position encoding)
-    unsigned long long mask = 0ull;   // ReLU bits of the layer just finished; stored after the next MFMA loop
+    mask_t mask = 0;   // ReLU bits of the layer just finished; stored after the next MFMA loop
     hidden_layer<ACT_RELU, TRAIN, PE_P>(act, pk + F_L0, pk + BIAS, ncol0, tid, wsp(WS_PE, PE_P), nullptr, nullptr, &mask);
     DIAG_STAMP(3);
     // L1..L4 (input tile = h(l-1))
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
     }
     // L5: [h4 | pe] in two passes over the same accumulators
     {
-        f32x16 acc[2][2];
+        f32x16 acc[MT][2];
         init_bias<2>(acc, pk + BIAS + 5 * H, ncol0, lane);
         mma_layer<2, TRAIN ? H : 0>(act, pk + F_L5A, H, H / 8, ncol0, lane, acc, wsp(WS_H + 4 * (size_t)H, H), tid);
         if constexpr (TRAIN) *mskp(4) = mask;
@@ -380,14 +389,14 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
     }
     // L9: 256 feature columns on MFMA, density column on the VALU
     {
-        f32x16 acc[2][2];
+        f32x16 acc[MT][2];
         init_bias<2>(acc, pk + BIAS + 9 * H, ncol0, lane);
         mma_layer<2, TRAIN ? H : 0>(act, pk + F_L9, H, H / 8, ncol0, lane, acc, wsp(WS_H + 8 * (size_t)H, H), tid);
         const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
         if constexpr (TRAIN) *mskp(8) = mask;
-        if ((tid & 3) == 0) {
-            sraw_s[tid >> 2] = s;
-            if constexpr (TRAIN) ws[WS_SRAW * Mp + m0 + (tid >> 2)] = s;
+        if (tid % TPS == 0) {
+            sraw_s[tid / TPS] = s;
+            if constexpr (TRAIN) ws[WS_SRAW * Mp + m0 + tid / TPS] = s;
         }
         __syncthreads();
         fwd_epilogue<2, ACT_NONE, false>(act, acc, ncol0, lane, nullptr, H);
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
     // L10: [f | de] -> 128, two passes
     {
         const int nc = wave * 32;
-        f32x16 acc[2][1];
+        f32x16 acc[MT][1];
         init_bias<1>(acc, pk + BIAS10, nc, lane);
         mma_layer<1, TRAIN ? H : 0>(act, pk + F_L10A, HH, H / 8, nc, lane, acc, wsp(WS_F, H), tid);
         __syncthreads();
@@ -412,13 +421,13 @@ __global__ __launch_bounds__(256, 2) void nerf_fwd_kernel(FwdArgs a) {
         DIAG_STAMP(17);
     }
     // L11 + sigmoid, density = relu(raw)
-    head_out(act, pk + W11, pk + BIAS11, 1.0f, fmaxf(sraw_s[tid >> 2], 0.0f), m0, a.M, a.colors, a.density, tid);
+    head_out(act, pk + W11, pk + BIAS11, 1.0f, fmaxf(sraw_s[tid / TPS], 0.0f), m0, a.M, a.colors, a.density, tid);
     if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
     DIAG_STAMP(18);
 }
 
 template <bool TRAIN>
-__global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__(256, WG_PER_CU) void siren_fwd_kernel(FwdArgs a) {
     using namespace lay;
     using namespace lay::siren;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
     float* sraw_s = xin + XIN_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t m0 = (size_t)blockIdx.x * TILE;
+    const size_t m0 = (size_t)blockIdx.x * TR;
     const float* __restrict__ pk = a.pk;
     float* ws = a.ws;
     const size_t Mp = a.Mp;
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
     load_inputs(a, m0, xin, tid);
     __syncthreads();
     if constexpr (TRAIN) {
-        if (tid < TILE) {
+        if (tid < TR) {
             f32x4 v = {xin[tid * 8], xin[tid * 8 + 1], xin[tid * 8 + 2], 0.0f};
             *reinterpret_cast<f32x4*>(ws + WS_X * Mp + (m0 + tid) * 4) = v;
         }
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
     {
         const float w0 = pk[W0 + tid * 3], w1 = pk[W0 + tid * 3 + 1], w2 = pk[W0 + tid * 3 + 2], b = pk[BIAS + tid];
         float* gc = wsp(WS_C, H);
-        for (int s = 0; s < TILE; ++s) {
+        for (int s = 0; s < TR; ++s) {
             const float z = fmaf(xin[s * 8 + 2], w2, fmaf(xin[s * 8 + 1], w1, fmaf(xin[s * 8], w0, b)));
             float sn, cs;
             nerf_sincosf(mul_rn(30.0f, z), &sn, &cs);
@@ -461,13 +470,13 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
                                         wsp(WS_H + (size_t)(l - 1) * H, H), wsp(WS_C + (size_t)l * H, H));
     // feature_remap on MFMA, density branch on the VALU (both read h7)
     {
-        f32x16 acc[2][2];
+        f32x16 acc[MT][2];
         init_bias<2>(acc, pk + BIAS + 8 * H, ncol0, lane);
         mma_layer<2, TRAIN ? H : 0>(act, pk + F_FEAT, H, H / 8, ncol0, lane, acc, wsp(WS_H + 7 * (size_t)H, H), tid);
         const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
-        if ((tid & 3) == 0) {
-            sraw_s[tid >> 2] = s;
-            if constexpr (TRAIN) ws[WS_SRAW * Mp + m0 + (tid >> 2)] = s;
+        if (tid % TPS == 0) {
+            sraw_s[tid / TPS] = s;
+            if constexpr (TRAIN) ws[WS_SRAW * Mp + m0 + tid / TPS] = s;
         }
         __syncthreads();
         fwd_epilogue<2, ACT_NONE, false>(act, acc, ncol0, lane, nullptr, H);
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
     }
     {
         const int nc = wave * 32;
-        f32x16 acc[2][1];
+        f32x16 acc[MT][1];
         init_bias<1>(acc, pk + BIAS_RGB, nc, lane);
         mma_layer<1, TRAIN ? H : 0>(act, pk + F_RGBA, HH, H / 8, nc, lane, acc, wsp(WS_F, H), tid);
         __syncthreads();
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void siren_fwd_kernel(FwdArgs a) {
         fwd_epilogue<1, ACT_SIN, TRAIN>(act, acc, nc, lane, wsp(WS_CG, HH), HH);
         __syncthreads();
     }
-    head_out(act, pk + WOUT, pk + BIAS_OUT, 1.0f, fmaxf(sraw_s[tid >> 2], 0.0f) * 10.0f, m0, a.M, a.colors, a.density,
+    head_out(act, pk + WOUT, pk + BIAS_OUT, 1.0f, fmaxf(sraw_s[tid / TPS], 0.0f) * 10.0f, m0, a.M, a.colors, a.density,
              tid);
     if constexpr (TRAIN) store_tile(act, HH, wsp(WS_G, HH), HH, tid);
 }
@@ -520,7 +529,7 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
                      (long long)M, S);
     }
     const size_t mp = lay::padded_samples(M);
-    const size_t tiles = mp / lay::TILE;
+    const size_t tiles = mp / TR;
     NERF_REQUIRE(tiles < (1ull << 31), "nerf_mlp_fwd: too many samples");
     FwdArgs a{packed, M, mp, points, dirs, rays_o, rays_d, t, S, t_per_ray, (float)near, (float)(far - near), colors, density, workspace};
 #ifdef NERF_DIAG
