@@ -4,14 +4,17 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of synthetic rays already resident in HBM:
-draw u, stratified t, fused sample+encode+MLP forward, compositing, MSE, compositing backward,
-fused MLP data-gradient chain, per-layer weight gradients, (N>1: one RCCL all-reduce of the flat
-gradient bucket), one fused Adam launch, weight re-pack.  Workload (the single-GPU training configuration the headline rate is quoted on):
-lego-shaped synthetic 800x800 scene, 4096 rays per GPU per step, 256 MLP evaluations per ray
-(the reference's num_samples = 256 single pass, config_lego.txt:15; same FLOPs as 64 coarse +
-64+128 fine), NeRF model, fp32.  Weak scaling: every rank renders its own 4096-ray slice of a
-4096*N batch and shares the uniform draw.
+A step = one pass of the hot path over one batch of synthetic rays already resident in HBM.
+Default workload (the single-GPU training configuration the headline rate is quoted on): lego-shaped
+synthetic 800x800 scene, 4096 rays per GPU per step, 64 coarse + 128 fine samples per ray through a
+coarse and a fine NeRF MLP, fp32 -- draw u, stratified t, coarse pass (fused sample+encode+MLP forward,
+compositing with weights), inverse-CDF re-sampling, fine pass over the merged 192 depths, both MSE
+losses, compositing backward, fused MLP data-gradient chains, per-layer weight gradients of both
+networks, (N>1: one RCCL all-reduce of the shared flat gradient bucket), one fused Adam launch, weight
+re-pack: 256 MLP evaluations per ray.  `--sampling single` is the reference's own single pass of
+num_samples = 256 (config_lego.txt:15; same FLOPs), `--model siren` its other network, `--mode infer`
+the gradient-free render (`--precision bf16`: the opt-in mode).  Weak scaling: every rank renders its
+own 4096-ray slice of a 4096*N batch with the same stratified draw.
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,14 +40,45 @@ FLOPS = {
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (without sparsity)
 PEAK_HBM_GBS = 8000.0
-# HBM bytes per MLP evaluation from the committed rocprofv3 --pmc passes (profiles/r1_pmc_fetch.csv,
-# r1_pmc_write.csv: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch / 1,048,576 samples; FETCH_SIZE
-# doubled as the gfx950 note on wide coalesced reads prescribes).  Counters cannot be read from
-# inside this process, so these are constants of the measured build, per sample.
-TRAFFIC_BYTES_PER_SAMPLE = {
-    ("nerf", "mlp_fwd_train"): (2 * 396256 + 11718656) * 1024 / 1048576,   # 12.2 KB: 11.4 KB activations + masks written
-    ("nerf", "mlp_bwd_data"): (2 * 731632 + 11030586) * 1024 / 1048576,    # 12.2 KB: 10.8 KB layer gradients written
-}
+PROFILES = os.path.join(ROOT, "profiles")
+# kernel-name fragments of the timed launches in the rocprofv3 counter summaries
+PMC_KERNEL = {("nerf", "mlp_fwd_train"): "nerf_fwd_kernel<true>", ("nerf", "mlp_bwd_data"): "nerf_dgrad_kernel",
+              ("nerf", "mlp_fwd_infer"): "nerf_fwd_kernel<false>", ("siren", "mlp_fwd_train"): "siren_fwd_kernel<true>",
+              ("siren", "mlp_bwd_data"): "siren_dgrad_kernel", ("siren", "mlp_fwd_infer"): "siren_fwd_kernel<false>"}
+
+
+def pmc_traffic_per_sample(model, kernel):
+    """HBM bytes per MLP evaluation of one kernel from the newest committed `rocprofv3 --pmc` passes
+    (profiles/r<N>_pmc_fetch.csv, r<N>_pmc_write.csv: profiles/summarize_pmc.py output, KiB per dispatch;
+    r<N>_pmc_meta.json names the samples per dispatch of that profiled command).  FETCH_SIZE is doubled:
+    on gfx950 it reports half the bytes of wide coalesced reads.  Counters cannot be read from inside
+    this process; the figure is per sample of the profiled build, so it is None when no pass is found."""
+    import csv
+    import glob
+    import re
+    frag = PMC_KERNEL.get((model, kernel))
+    metas = sorted(glob.glob(os.path.join(PROFILES, "r*_pmc_meta.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_pmc_meta", f).group(1)))
+    if frag is None or not metas:
+        return None, None
+    with open(metas[-1]) as f:
+        meta = json.load(f)
+    tag = os.path.basename(metas[-1]).split("_pmc_meta")[0]
+    kib = {}
+    files = []
+    for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        path = os.path.join(PROFILES, f"{tag}_pmc_{which}.csv")
+        if not os.path.exists(path):
+            return None, None
+        files.append(os.path.relpath(path, ROOT))
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if frag in row["kernel"] and row["counter"] == counter:
+                    kib[counter] = float(row["mean_per_dispatch"])
+    if len(kib) != 2:
+        return None, None
+    per_sample = (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0 / float(meta["samples_per_dispatch"])
+    return per_sample, files + [os.path.relpath(metas[-1], ROOT)]
 
 
 def make_rays(n_views, H, W, device, seed=42):
@@ -81,9 +115,9 @@ def _pose_spherical(theta, phi, radius):
     return (swap @ (ry @ (rx @ t))).astype(np.float32)
 
 
-def cpu_baseline(model_name, rays, samples, hier=False, n_coarse=64, n_fine=128, steps=2):
+def cpu_baseline(model_name, rays, samples, hier=False, n_coarse=64, n_fine=128, steps=5, warmup=2):
     """The CPU restatement (oracle) timed on the host cores: same step (render, MSE, backward,
-    Adam) on a bounded sample of the same workload."""
+    Adam) on a bounded sample of the same workload; median of `steps` steps after `warmup` untimed ones."""
     from oracle import nerf_oracle as O
     torch.manual_seed(0)
     is_nerf = model_name == "nerf"
@@ -100,7 +134,7 @@ def cpu_baseline(model_name, rays, samples, hier=False, n_coarse=64, n_fine=128,
     m = [torch.zeros_like(p) for p in allp]
     v = [torch.zeros_like(p) for p in allp]
     times = []
-    for it in range(steps + 1):
+    for it in range(steps + warmup):
         t0 = time.perf_counter()
         if hier:
             rc, rf, _, _ = O.render_hierarchical(lambda x, dd: fwd(params, x, dd), lambda x, dd: fwd(params2, x, dd), o, d,
@@ -114,10 +148,11 @@ def cpu_baseline(model_name, rays, samples, hier=False, n_coarse=64, n_fine=128,
             for i, (p, g) in enumerate(zip(allp, grads)):
                 O.adam_step(p, g, m[i], v[i], it + 1, 5e-4)
         times.append(time.perf_counter() - t0)
-    best = float(np.median(times[1:]))
+    best = float(np.median(times[warmup:]))
     return {"value": rays / best, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{rays} rays x {samples} MLP evaluations/ray ({'coarse+fine' if hier else 'single pass'}), {model_name}, "
-                      f"fwd+bwd+Adam, median of {steps} steps after 1 warm-up (oracle/nerf_oracle.py, torch CPU fp32)"}
+                      f"fwd+bwd+Adam, median of {steps} steps after {warmup} warm-ups (oracle/nerf_oracle.py, torch CPU fp32, "
+                      f"{torch.get_num_threads()} threads)"}
 
 
 def main():
@@ -143,6 +178,7 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -287,11 +323,13 @@ def main():
             ach = kernels[dom]["tflops"]
             per_sample = dict((n_, f_) for n_, f_, _ in specs)[dom]
             samples_per_launch = kernels[dom]["flop_per_launch"] / per_sample
-            tb = TRAFFIC_BYTES_PER_SAMPLE.get((args.model, dom))
+            tb, tb_files = pmc_traffic_per_sample(args.model, dom)
             peak = PEAK_BF16_MFMA_TFLOPS if dom.endswith("bf16") else PEAK_F32_MFMA_TFLOPS
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                     "frac": ach / peak, "traffic": tb * samples_per_launch if tb else None,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc passes of this build, profiles/)",
+                    "traffic_unit": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) per sample of the rocprofv3 --pmc "
+                                    "passes in traffic_source x samples of this launch",
+                    "traffic_source": tb_files,
                     "ms_per_launch": kernels[dom]["ms_per_launch"], "flop_per_launch": kernels[dom]["flop_per_launch"],
                     "flop_per_sample": per_sample, "samples_per_launch": samples_per_launch}
         total_flop = sum(k["flop_per_launch"] * k["launches_per_step"] for k in kernels.values())
@@ -317,7 +355,7 @@ def main():
             "final_value": final,
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":
-            res["cpu_baseline"] = cpu_baseline(args.model, args.cpu_rays, S, hier, args.coarse, args.fine)
+            res["cpu_baseline"] = cpu_baseline(args.model, args.cpu_rays, S, hier, args.coarse, args.fine, steps=args.cpu_steps)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

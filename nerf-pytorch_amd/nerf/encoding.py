@@ -1,8 +1,7 @@
 """Positional encoding as a HIP kernel (drop-in for the reference's nerf/encoding.py)."""
 import torch
 
-from . import _hip
-from .ops import _f32c
+from .ops import posenc_op
 
 
 def positional_encoding(x: torch.Tensor, L: int) -> torch.Tensor:
@@ -12,4 +11,4 @@ def positional_encoding(x: torch.Tensor, L: int) -> torch.Tensor:
     never need gradients with respect to positions."""
     if x.requires_grad:
         raise NotImplementedError("positional_encoding: gradient with respect to x is not provided")
-    return _hip.posenc(_f32c(x), int(L))
+    return posenc_op(x, int(L))

@@ -1,9 +1,20 @@
-"""Autograd bridges between PyTorch and the HIP kernels (no arithmetic here)."""
-from __future__ import annotations
+"""The HIP kernels as PyTorch custom operators (torch.library, namespace `nerf`) with their autograd
+formulas and shape-only fake implementations, so that the dispatcher, torch.compile and opcheck see
+them; no arithmetic happens here.  Operators:
 
-from typing import Sequence
+    nerf::posenc(x, L)                                   nerf/encoding.py:4-20
+    nerf::composite(colors, densities, deltas, white)    nerf/rendering.py:125-153 (+ nerf::composite_backward)
+    nerf::mlp(model, packed, points, dirs, params, ...)  nerf/models.py:62-75 / :185-203 (+ nerf::mlp_backward)
+    nerf::render(model, packed, rays_o, rays_d, t, ...)  one ray chunk of nerf/rendering.py:191-223: sample ->
+                                                         encode -> MLP -> composite (+ nerf::render_backward)
+
+`MLPFunction`, `RenderFunction` and `CompositeFunction` keep the call forms the rest of the package uses.
+"""
+from typing import List, Optional, Sequence, Tuple
 
 import torch
+from torch import Tensor
+from torch.library import custom_op
 
 from . import _hip
 
@@ -74,48 +85,148 @@ def _check_sink(sink, model_id) -> None:
         raise ValueError("gradient sink must be None or the flat fp32 gradient buffer of the whole model")
 
 
-def _param_grads(ctx, flat):
-    if ctx.sink_used:
-        return (None,) * ctx.nparams
+def _split(flat: Tensor, shapes) -> List[Tensor]:
+    """Per-tensor views of a flat gradient buffer (state_dict order)."""
     grads, off = [], 0
-    for shp in ctx.shapes:
+    for shp in shapes:
         n = 1
         for s in shp:
-            n *= s
+            n *= int(s)
         grads.append(flat[off:off + n].view(shp))
         off += n
-    return tuple(grads)
+    return grads
 
 
-class MLPFunction(torch.autograd.Function):
-    """(colors, density) = model(points, dirs) through the fused encode+MLP kernel;
-    backward yields the 24 parameter gradients (flat buffer, state_dict order)."""
+def _none_tensor(like: Tensor) -> Tensor:
+    """Stand-in for an output the call does not produce (operators cannot return None)."""
+    return like.new_empty((0,), dtype=torch.float32)
+
+
+def _opaque(ws, like: Tensor) -> Tensor:
+    """The forward workspace as an operator output: raw 32-bit words (it mixes activations with ReLU mask
+    bits, which are not numbers), empty for an inference call."""
+    return ws.view(torch.int32) if ws is not None else like.new_empty((0,), dtype=torch.int32)
+
+
+# ------------------------------------------------------------------------------------------- posenc
+@custom_op("nerf::posenc", mutates_args=())
+def posenc_op(x: Tensor, L: int) -> Tensor:
+    return _hip.posenc(_f32c(x), int(L))
+
+
+@posenc_op.register_fake
+def _(x, L):
+    return x.new_empty((x.shape[0], x.shape[1] * (1 + 2 * L)))
+
+
+# ---------------------------------------------------------------------------------------- composite
+@custom_op("nerf::composite", mutates_args=())
+def composite_op(colors: Tensor, densities: Tensor, deltas: Tensor, white: bool) -> Tensor:
+    rgb, _, _, _ = _hip.composite_fwd(_f32c(colors), _f32c(densities), _f32c(deltas), white)
+    return rgb
+
+
+@composite_op.register_fake
+def _(colors, densities, deltas, white):
+    return densities.new_empty((densities.shape[0], 3))
+
+
+@custom_op("nerf::composite_backward", mutates_args=())
+def composite_backward_op(colors: Tensor, densities: Tensor, deltas: Tensor, white: bool,
+                          grad_rgb: Tensor) -> Tuple[Tensor, Tensor]:
+    return _hip.composite_bwd(_f32c(colors), _f32c(densities), _f32c(deltas), white, _f32c(grad_rgb))
+
+
+@composite_backward_op.register_fake
+def _(colors, densities, deltas, white, grad_rgb):
+    return torch.empty_like(colors, memory_format=torch.contiguous_format), \
+        torch.empty_like(densities, memory_format=torch.contiguous_format)
+
+
+def _composite_setup(ctx, inputs, output):
+    colors, densities, deltas, white = inputs
+    ctx.save_for_backward(colors, densities, deltas)
+    ctx.white = bool(white)
+
+
+def _composite_backward(ctx, grad_rgb):
+    colors, densities, deltas = ctx.saved_tensors
+    dcolors, ddens = composite_backward_op(colors, densities, deltas, ctx.white, grad_rgb)
+    return dcolors, ddens, None, None
+
+
+composite_op.register_autograd(_composite_backward, setup_context=_composite_setup)
+
+
+# ---------------------------------------------------------------------------------------------- MLP
+def _ws_floats(model: int, M: int, train: bool) -> int:
+    return int(_hip.lib.nerf_mlp_fwd_workspace_floats(model, M)) if train else 0
+
+
+@custom_op("nerf::mlp", mutates_args=())
+def mlp_op(model: int, packed: Tensor, points: Tensor, dirs: Tensor, params: Sequence[Tensor], train: bool,
+           sink: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """(colors [M,3], density [M], workspace) = model(points, dirs) through the fused encode + MLP kernel.
+    `packed` is the weight image of `params` (which are inputs only so that autograd routes the 24 parameter
+    gradients); `sink`, when given, is the flat gradient bucket the backward adds into instead."""
+    _check_sink(sink, model)
+    colors, density, ws = _mlp_fwd(model, packed, points.shape[0], train, points=_f32c(points), dirs=_f32c(dirs))
+    return colors, density, _opaque(ws, colors)
+
+
+@mlp_op.register_fake
+def _(model, packed, points, dirs, params, train, sink):
+    M = points.shape[0]
+    return (points.new_empty((M, 3)), points.new_empty((M,)),
+            points.new_empty((_ws_floats(model, M, train),), dtype=torch.int32))
+
+
+@custom_op("nerf::mlp_backward", mutates_args=("sink",))
+def mlp_backward_op(model: int, packed: Tensor, dcolors: Tensor, ddensity: Tensor, colors: Tensor, workspace: Tensor,
+                    sink: Optional[Tensor]) -> Tensor:
+    """Flat parameter gradient (state_dict order) of nerf::mlp; with `sink` it is ADDED to that buffer and an
+    empty tensor is returned."""
+    flat = _hip.mlp_bwd(model, packed, colors.shape[0], _f32c(dcolors), _f32c(ddensity), colors,
+                        workspace.view(torch.float32), sink, sink is not None)
+    return _none_tensor(colors) if sink is not None else flat
+
+
+@mlp_backward_op.register_fake
+def _(model, packed, dcolors, ddensity, colors, workspace, sink):
+    return colors.new_empty((0 if sink is not None else _hip.param_floats(model),))
+
+
+def _mlp_setup(ctx, inputs, output):
+    model, packed, points, dirs, params, train, sink = inputs
+    colors, density, ws = output
+    ctx.model, ctx.train, ctx.sink = model, bool(train), sink
+    ctx.shapes = [p.shape for p in params]
+    ctx.save_for_backward(packed, colors, ws)
+
+
+def _mlp_backward(ctx, dcolors, ddensity, dws):
+    if not ctx.train:
+        raise RuntimeError("backward through an inference-mode forward")
+    packed, colors, ws = ctx.saved_tensors
+    if dcolors is None:
+        dcolors = torch.zeros_like(colors)
+    if ddensity is None:
+        ddensity = colors.new_zeros((colors.shape[0],))
+    flat = mlp_backward_op(ctx.model, packed, dcolors, ddensity, colors, ws, ctx.sink)
+    grads = [None] * len(ctx.shapes) if ctx.sink is not None else _split(flat, ctx.shapes)
+    return None, None, None, None, grads, None, None
+
+
+mlp_op.register_autograd(_mlp_backward, setup_context=_mlp_setup)
+
+
+class MLPFunction:
+    """(colors, density) = model(points, dirs); call form kept from the autograd.Function this replaced."""
 
     @staticmethod
-    def forward(ctx, model_id, packed, points, dirs, train, sink, *params):
-        M = points.shape[0]
-        colors, density, ws = _mlp_fwd(model_id, packed, M, train, points=points, dirs=dirs)
-        ctx.model_id, ctx.M, ctx.train = model_id, M, train
-        ctx.nparams = len(params)
-        _check_sink(sink, model_id)
-        ctx.sink, ctx.sink_used = sink, sink is not None
-        if train:
-            ctx.save_for_backward(packed, colors, ws)
-            ctx.shapes = [p.shape for p in params]
+    def apply(model_id, packed, points, dirs, train, sink, *params):
+        colors, density, _ = mlp_op(model_id, packed, points, dirs, list(params), bool(train), sink)
         return colors, density
-
-    @staticmethod
-    def backward(ctx, dcolors, ddensity):
-        if not ctx.train:
-            raise RuntimeError("backward through an inference-mode forward")
-        packed, colors, ws = ctx.saved_tensors
-        if dcolors is None:
-            dcolors = torch.zeros_like(colors)
-        if ddensity is None:
-            ddensity = torch.zeros((ctx.M,), dtype=torch.float32, device=colors.device)
-        flat = _hip.mlp_bwd(ctx.model_id, packed, ctx.M, _f32c(dcolors), _f32c(ddensity), colors, ws, ctx.sink,
-                            ctx.sink_used)
-        return (None,) * 6 + _param_grads(ctx, flat)
 
 
 class LinearActFunction(torch.autograd.Function):
@@ -147,59 +258,93 @@ class LinearActFunction(torch.autograd.Function):
         return dx, dW, db, None, None, None
 
 
-class RenderFunction(torch.autograd.Function):
-    """rgb = composite(model(sample(rays, t))) for one ray chunk: positions are generated
-    inside the MLP kernel, colors/densities go straight to the compositing kernel."""
+# ------------------------------------------------------------------------------------------- render
+@custom_op("nerf::render", mutates_args=())
+def render_op(model: int, packed: Tensor, rays_o: Tensor, rays_d: Tensor, t: Tensor, deltas: Tensor, near: float,
+              far: float, white: bool, extras: bool, params: Sequence[Tensor], train: bool,
+              sink: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """One ray chunk: rgb = composite(model(sample(rays, t))).  Positions are generated inside the MLP kernel,
+    colors / densities go straight to the compositing kernel.  t, deltas: [S] (shared) or [R,S] (per ray).
+    Returns rgb [R,3], weights [R,S], depth [R], acc [R] (empty unless `extras`), and what the backward needs:
+    colors [R,S,3], density [R,S], workspace (empty unless `train`)."""
+    _check_sink(sink, model)
+    R, S = rays_o.shape[0], t.shape[-1]
+    t, deltas = _f32c(t), _f32c(deltas)
+    colors, density, ws = _mlp_fwd(model, packed, R * S, train, rays_o=_f32c(rays_o), rays_d=_f32c(rays_d), t=t, S=S,
+                                   near=near, far=far)
+    colors, density = colors.view(R, S, 3), density.view(R, S)
+    rgb, weights, depth, acc = _hip.composite_fwd(colors, density, deltas, white, t=t, want_weights=extras,
+                                                  want_depth=extras, want_acc=extras)
+    none = _none_tensor(rgb)
+    return (rgb, weights if extras else none, depth if extras else _none_tensor(rgb), acc if extras else _none_tensor(rgb),
+            colors, density, _opaque(ws, rgb))
+
+
+@render_op.register_fake
+def _(model, packed, rays_o, rays_d, t, deltas, near, far, white, extras, params, train, sink):
+    R, S = rays_o.shape[0], t.shape[-1]
+    e = rays_o.new_empty
+    return (e((R, 3)), e((R, S) if extras else (0,)), e((R,) if extras else (0,)), e((R,) if extras else (0,)),
+            e((R, S, 3)), e((R, S)), e((_ws_floats(model, R * S, train),), dtype=torch.int32))
+
+
+@custom_op("nerf::render_backward", mutates_args=("sink",))
+def render_backward_op(model: int, packed: Tensor, colors: Tensor, density: Tensor, deltas: Tensor, white: bool,
+                       grad_rgb: Tensor, workspace: Tensor, sink: Optional[Tensor]) -> Tensor:
+    """Flat parameter gradient of nerf::render: compositing backward, then the MLP backward; with `sink` the
+    result is ADDED to that buffer and an empty tensor is returned."""
+    dcolors, ddens = _hip.composite_bwd(colors, density, deltas, white, _f32c(grad_rgb))
+    flat = _hip.mlp_bwd(model, packed, density.numel(), dcolors.view(-1, 3), ddens.view(-1), colors.view(-1, 3),
+                        workspace.view(torch.float32), sink, sink is not None)
+    return _none_tensor(colors) if sink is not None else flat
+
+
+@render_backward_op.register_fake
+def _(model, packed, colors, density, deltas, white, grad_rgb, workspace, sink):
+    return colors.new_empty((0 if sink is not None else _hip.param_floats(model),))
+
+
+def _render_setup(ctx, inputs, output):
+    model, packed, rays_o, rays_d, t, deltas, near, far, white, extras, params, train, sink = inputs
+    rgb, weights, depth, acc, colors, density, ws = output
+    ctx.model, ctx.train, ctx.sink, ctx.white = model, bool(train), sink, bool(white)
+    ctx.shapes = [p.shape for p in params]
+    ctx.save_for_backward(packed, colors, density, _f32c(deltas), ws)
+
+
+def _render_backward(ctx, grad_rgb, *unused):
+    if not ctx.train:
+        raise RuntimeError("backward through an inference-mode forward")
+    packed, colors, density, deltas, ws = ctx.saved_tensors
+    if grad_rgb is None:
+        grad_rgb = colors.new_zeros((colors.shape[0], 3))
+    flat = render_backward_op(ctx.model, packed, colors, density, deltas, ctx.white, grad_rgb, ws, ctx.sink)
+    grads = [None] * len(ctx.shapes) if ctx.sink is not None else _split(flat, ctx.shapes)
+    return (None,) * 10 + (grads, None, None)
+
+
+render_op.register_autograd(_render_backward, setup_context=_render_setup)
+
+
+class RenderFunction:
+    """rgb (or rgb, weights, depth, acc with want_extras) of one ray chunk; call form kept from the
+    autograd.Function this replaced.  Only rgb carries a gradient."""
 
     @staticmethod
-    def forward(ctx, model_id, packed, rays_o, rays_d, t, deltas, near, far, white, want_extras, train, sink, *params):
-        R, S = rays_o.shape[0], t.shape[-1]   # t is [S] (shared) or [R,S] (per ray)
-        M = R * S
-        colors, density, ws = _mlp_fwd(model_id, packed, M, train, rays_o=rays_o, rays_d=rays_d, t=t, S=S, near=near,
-                                       far=far)
-        colors = colors.view(R, S, 3)
-        density = density.view(R, S)
-        rgb, weights, depth, acc = _hip.composite_fwd(colors, density, deltas, white, t=t, want_weights=want_extras,
-                                                      want_depth=want_extras, want_acc=want_extras)
-        ctx.model_id, ctx.M, ctx.train, ctx.white = model_id, M, train, bool(white)
-        ctx.nparams = len(params)
-        _check_sink(sink, model_id)
-        ctx.sink, ctx.sink_used = sink, sink is not None
-        if train:
-            ctx.save_for_backward(packed, colors, density, deltas, ws)
-            ctx.shapes = [p.shape for p in params]
+    def apply(model_id, packed, rays_o, rays_d, t, deltas, near, far, white, want_extras, train, sink, *params):
+        out = render_op(model_id, packed, rays_o, rays_d, t, deltas, float(near), float(far), bool(white),
+                        bool(want_extras), list(params), bool(train), sink)
         if want_extras:
-            ctx.mark_non_differentiable(weights, depth, acc)
-            return rgb, weights, depth, acc
-        return rgb
+            return out[0], out[1].detach(), out[2].detach(), out[3].detach()
+        return out[0]
+
+
+class CompositeFunction:
+    """composite_volume for arbitrary upstream models (colors / densities carry grad)."""
 
     @staticmethod
-    def backward(ctx, grad_rgb, *unused):
-        if not ctx.train:
-            raise RuntimeError("backward through an inference-mode forward")
-        packed, colors, density, deltas, ws = ctx.saved_tensors
-        dcolors, ddens = _hip.composite_bwd(colors, density, deltas, ctx.white, _f32c(grad_rgb))
-        flat = _hip.mlp_bwd(ctx.model_id, packed, ctx.M, dcolors.view(-1, 3), ddens.view(-1), colors.view(-1, 3), ws,
-                            ctx.sink, ctx.sink_used)
-        return (None,) * 12 + _param_grads(ctx, flat)
-
-
-class CompositeFunction(torch.autograd.Function):
-    """composite_volume for arbitrary upstream models (colors/densities carry grad)."""
-
-    @staticmethod
-    def forward(ctx, colors, densities, deltas, white):
-        colors, densities, deltas = _f32c(colors), _f32c(densities), _f32c(deltas)
-        rgb, _, _, _ = _hip.composite_fwd(colors, densities, deltas, white)
-        ctx.save_for_backward(colors, densities, deltas)
-        ctx.white = bool(white)
-        return rgb
-
-    @staticmethod
-    def backward(ctx, grad_rgb):
-        colors, densities, deltas = ctx.saved_tensors
-        dcolors, ddens = _hip.composite_bwd(colors, densities, deltas, ctx.white, _f32c(grad_rgb))
-        return dcolors, ddens, None, None
+    def apply(colors, densities, deltas, white):
+        return composite_op(colors, densities, deltas, bool(white))
 
 
 class ExclusiveCumprodFunction(torch.autograd.Function):

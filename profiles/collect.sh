@@ -1,0 +1,44 @@
+#!/bin/bash
+# Collects the profiles of one round on the GPU box (run from the repository root through gpurun):
+#   bash profiles/collect.sh r2
+# writes gpurun_out/<tag>/prof/<tag>_*.csv|json|jsonl; copy what should be judged into profiles/.
+#   * rocprofv3 --kernel-trace --stats of the default bench command and of its other modes
+#   * separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ) of the single-pass workload, where every
+#     fused launch covers exactly 1,048,576 samples (the figure <tag>_pmc_meta.json records for bench.py)
+#   * bench.py lines of the other modes (builder-run, kept next to the profiles)
+set -u
+TAG=${1:-r2}
+OUT=$PWD/gpurun_out/$TAG/prof
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+stats() {   # name, bench arguments...
+    local name=$1; shift
+    rm -rf "$OUT/kt_$name"
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt_$name" -o p --output-format csv -- python3 bench.py "$@" --no-cpu-baseline \
+        > "$OUT/${TAG}_bench_${name}_profiled.json" 2> "$OUT/kt_$name.log" || return 1
+    cp "$(find "$OUT/kt_$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_${name}_kernel_stats.csv"
+}
+pmc() {     # name, counters...
+    local name=$1; shift
+    rm -rf "$OUT/pmc_$name"
+    timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$OUT/pmc_$name" -o p --output-format csv -- python3 bench.py --sampling single --steps 3 --warmup 1 --no-cpu-baseline \
+        > /dev/null 2> "$OUT/pmc_$name.log" || return 1
+    python3 profiles/summarize_pmc.py "$OUT/pmc_$name" > "$OUT/${TAG}_pmc_$name.csv"
+}
+stats hier --steps 6 --warmup 2 &&
+stats single --steps 6 --warmup 2 --sampling single &&
+stats siren --steps 6 --warmup 2 --sampling single --model siren &&
+pmc fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
+pmc write WRITE_SIZE &&
+pmc sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
+echo '{"samples_per_dispatch": 1048576, "command": "rocprofv3 --pmc <counters> -- python3 bench.py --sampling single --steps 3 --warmup 1 --no-cpu-baseline", "unit": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (profiles/summarize_pmc.py means)"}' > "$OUT/${TAG}_pmc_meta.json" &&
+{
+  : > "$OUT/${TAG}_bench_modes.jsonl"
+  for args in "--sampling single" "--sampling single --model siren" "--model siren" "--mode infer" "--mode infer --sampling single" \
+              "--mode infer --precision bf16" "--mode infer --precision bf16 --rays 32768" "--mode infer --rays 640000 --steps 3 --warmup 1" \
+              "--rays 1024" "--rays 16384"; do
+      timeout -k 10 300 python3 bench.py $args --no-cpu-baseline >> "$OUT/${TAG}_bench_modes.jsonl" 2>> "$OUT/modes.err" || exit 1
+  done
+} &&
+timeout -k 10 300 python3 bench_kernels.py > "$OUT/${TAG}_hbm_kernels.jsonl" 2> "$OUT/hbm.err" &&
+echo "profiles collected in $OUT"
