@@ -201,6 +201,7 @@ def _mlp_setup(ctx, inputs, output):
     colors, density, ws = output
     ctx.model, ctx.train, ctx.sink = model, bool(train), sink
     ctx.shapes = [p.shape for p in params]
+    ctx.set_materialize_grads(False)   # no zero tensors for the outputs nobody differentiates (the workspace!)
     ctx.save_for_backward(packed, colors, ws)
 
 
@@ -208,6 +209,8 @@ def _mlp_backward(ctx, dcolors, ddensity, dws):
     if not ctx.train:
         raise RuntimeError("backward through an inference-mode forward")
     packed, colors, ws = ctx.saved_tensors
+    if dcolors is None and ddensity is None:
+        return None, None, None, None, [None] * len(ctx.shapes), None, None
     if dcolors is None:
         dcolors = torch.zeros_like(colors)
     if ddensity is None:
@@ -309,6 +312,7 @@ def _render_setup(ctx, inputs, output):
     rgb, weights, depth, acc, colors, density, ws = output
     ctx.model, ctx.train, ctx.sink, ctx.white = model, bool(train), sink, bool(white)
     ctx.shapes = [p.shape for p in params]
+    ctx.set_materialize_grads(False)   # no zero tensors for the outputs nobody differentiates (the workspace!)
     ctx.save_for_backward(packed, colors, density, _f32c(deltas), ws)
 
 
@@ -316,8 +320,8 @@ def _render_backward(ctx, grad_rgb, *unused):
     if not ctx.train:
         raise RuntimeError("backward through an inference-mode forward")
     packed, colors, density, deltas, ws = ctx.saved_tensors
-    if grad_rgb is None:
-        grad_rgb = colors.new_zeros((colors.shape[0], 3))
+    if grad_rgb is None:   # only the extras were used downstream: they carry no gradient
+        return (None,) * 10 + ([None] * len(ctx.shapes), None, None)
     flat = render_backward_op(ctx.model, packed, colors, density, deltas, ctx.white, grad_rgb, ws, ctx.sink)
     grads = [None] * len(ctx.shapes) if ctx.sink is not None else _split(flat, ctx.shapes)
     return (None,) * 10 + (grads, None, None)
