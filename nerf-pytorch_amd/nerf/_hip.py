@@ -113,6 +113,8 @@ class KernelTimers:
             return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
+        if torch.cuda.current_stream() != torch.cuda.default_stream():
+            name += "@side"   # launched on a side stream: runs concurrently with the main stream's kernels
         self.events.setdefault(name, []).append((a, b, work))
         return b
 

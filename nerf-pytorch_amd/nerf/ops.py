@@ -10,6 +10,7 @@ them; no arithmetic happens here.  Operators:
 
 `MLPFunction`, `RenderFunction` and `CompositeFunction` keep the call forms the rest of the package uses.
 """
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -83,6 +84,32 @@ def _check_sink(sink, model_id) -> None:
     if sink is not None and (not isinstance(sink, torch.Tensor) or sink.dim() != 1
                              or sink.numel() != _hip.param_floats(model_id) or sink.dtype != torch.float32):
         raise ValueError("gradient sink must be None or the flat fp32 gradient buffer of the whole model")
+
+
+# A coarse + fine pair has two independent backward chains (each network's data- and weight-gradient
+# kernels).  Run on two streams they overlap on the device: the tail of one launch, where compute units run
+# out of tiles, is filled with the other chain's workgroups.  The coarse pass of render_nerf_hierarchical is
+# therefore issued on a side stream; autograd runs its backward there too.
+_side_streams = {}
+OVERLAP_BACKWARD = os.environ.get("NERF_OVERLAP", "1") != "0"
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _side_streams:
+        _side_streams[idx] = torch.cuda.Stream(device=idx)
+    return _side_streams[idx]
+
+
+def _join_after_backward(device) -> None:
+    """Called inside a backward that ran on the side stream and wrote into a gradient sink (which autograd does
+    not track): make the stream that called backward() wait for it, once the whole backward pass is queued."""
+    if torch.cuda.current_stream(device) is not None and torch.cuda.current_stream(device) == _side_streams.get(
+            torch.device(device).index):
+        done = torch.cuda.Event()
+        done.record()
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(device).wait_event(done))
 
 
 def _split(flat: Tensor, shapes) -> List[Tensor]:
@@ -323,6 +350,8 @@ def _render_backward(ctx, grad_rgb, *unused):
     if grad_rgb is None:   # only the extras were used downstream: they carry no gradient
         return (None,) * 10 + ([None] * len(ctx.shapes), None, None)
     flat = render_backward_op(ctx.model, packed, colors, density, deltas, ctx.white, grad_rgb, ws, ctx.sink)
+    if ctx.sink is not None:
+        _join_after_backward(colors.device)
     grads = [None] * len(ctx.shapes) if ctx.sink is not None else _split(flat, ctx.shapes)
     return (None,) * 10 + (grads, None, None)
 

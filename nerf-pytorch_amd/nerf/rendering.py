@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
-from . import _hip
+from . import _hip, ops
 from .ops import CompositeFunction, ExclusiveCumprodFunction, RenderFunction, _f32c, grad_sink, wants_grad
 
 
@@ -180,8 +180,20 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
         o, d = rays_o[i:i + chunk_size], rays_d[i:i + chunk_size]
         R = o.shape[0]
         t_c, deltas_c = _t_and_deltas(near, far, num_coarse, rays_o.device, None if u is None else u[ci].to(rays_o.device))
-        rgb_c, w_c, _, _ = RenderFunction.apply(coarse.model_id, wc, o, d, t_c, deltas_c, float(near), float(far),
-                                                bool(white_background), True, tc_train, sink_c, *pc)
+        if ops.OVERLAP_BACKWARD and tc_train and tf_train:
+            # the coarse pass goes to a side stream so that autograd runs its backward there, concurrently with
+            # the fine network's backward; in the forward direction the fine pass waits for it as before
+            main, side = torch.cuda.current_stream(rays_o.device), ops.side_stream(rays_o.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rgb_c, w_c, _, _ = RenderFunction.apply(coarse.model_id, wc, o, d, t_c, deltas_c, float(near), float(far),
+                                                        bool(white_background), True, tc_train, sink_c, *pc)
+            main.wait_stream(side)
+            rgb_c.record_stream(main)
+            w_c.record_stream(main)
+        else:
+            rgb_c, w_c, _, _ = RenderFunction.apply(coarse.model_id, wc, o, d, t_c, deltas_c, float(near), float(far),
+                                                    bool(white_background), True, tc_train, sink_c, *pc)
         with torch.no_grad():
             t_mid = (0.5 * (t_c[1:] + t_c[:-1])).expand(R, -1).contiguous()          # [R, Nc-1] bin edges
             cdf = _hip.weights_to_cdf(w_c[:, 1:-1].contiguous())                      # [R, Nc-1]
