@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 6
+#define NERF_ABI_VERSION 7
 
 #define NERF_OK 0
 #define NERF_E_ARG (-1)      /* bad shape / size / unsupported configuration */
@@ -60,6 +60,10 @@ int nerf_compute_rays(const float* c2w, int64_t N, int H, int W, double focal, f
  * out[m,:] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)], x: [M,D],
  * out: [M, D*(1+2L)], each sin/cos block D wide.  1 <= D <= 4, 0 <= L <= 16. */
 int nerf_posenc_fwd(const float* x, int64_t M, int D, int L, float* out, void* stream);
+
+/* What autograd derives for nerf/encoding.py:15-20 wrt x: grad_out [M, D*(1+2L)] -> dx [M,D] =
+ * g_x + sum_j 2^j (g_sin_j cos(2^j x) - g_cos_j sin(2^j x)). */
+int nerf_posenc_bwd(const float* x, const float* grad_out, int64_t M, int D, int L, float* dx, void* stream);
 
 /* ---- compositing: nerf/rendering.py:110-153 (compute_accumulated_transmittance,
  * composite_volume) ------------------------------------------------------------------------

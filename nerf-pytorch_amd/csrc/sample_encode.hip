@@ -163,6 +163,43 @@ extern "C" int nerf_posenc_fwd(const float* x, int64_t M, int D, int L, float* o
     return nerf_check_launch("nerf_posenc_fwd");
 }
 
+// gradient of the encoding wrt x (what autograd derives for nerf/encoding.py:15-20):
+//   dx[m,c] = g[m,c] + sum_j 2^j * (g_sin[j][m,c] * cos(2^j x) - g_cos[j][m,c] * sin(2^j x))
+// one thread per input element; sin/cos are recomputed with the forward's routine.
+__global__ __launch_bounds__(256) void posenc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        int64_t n, int D, int L, float* __restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t m = i / D;
+    const int c = (int)(i - m * D);
+    const int width = D * (1 + 2 * L);
+    const float* row = g + m * width;
+    const float v = x[i];
+    float acc = row[c];
+    float scale = 1.0f;
+#pragma unroll 1
+    for (int j = 0; j < L; ++j) {
+        float sn, cs;
+        nerf_sincosf(mul_rn(scale, v), &sn, &cs);
+        acc += scale * (row[D + 2 * D * j + c] * cs - row[D + 2 * D * j + D + c] * sn);
+        scale *= 2.0f;
+    }
+    dx[i] = acc;
+}
+
+extern "C" int nerf_posenc_bwd(const float* x, const float* grad_out, int64_t M, int D, int L, float* dx, void* stream) {
+    NERF_REQUIRE(M >= 0 && D >= 1 && D <= 4 && L >= 0 && L <= 16, "nerf_posenc_bwd: bad M=%lld D=%d L=%d",
+                 (long long)M, D, L);
+    if (M == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(x);
+    NERF_REQUIRE_PTR(grad_out);
+    NERF_REQUIRE_PTR(dx);
+    const int64_t blocks = ceil_div64(M * D, 256);
+    NERF_REQUIRE(blocks < (1ll << 31), "nerf_posenc_bwd: too many elements");
+    posenc_bwd_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(x, grad_out, M * D, D, L, dx);
+    return nerf_check_launch("nerf_posenc_bwd");
+}
+
 // ---------------------------------------------------------------------------------------
 // inverse-CDF sampling (no reference counterpart; canonical NeRF sample_pdf), in two steps:
 //   weights -> CDF   (normalise w+1e-5, running sum; fp32, tolerance-tested)

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 MODEL_NERF = 0
 MODEL_SIREN = 1
 NUM_PARAM_TENSORS = 24
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -38,6 +38,7 @@ _SIGS = {
     "nerf_exclusive_cumprod": (c_int, [_P, c_int64, c_int, _P, _P]),
     "nerf_exclusive_cumprod_bwd": (c_int, [_P, _P, c_int64, c_int, _P, _P]),
     "nerf_posenc_fwd": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
+    "nerf_posenc_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "nerf_composite_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "nerf_composite_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
     "nerf_mlp_param_floats": (c_size_t, [c_int]),
@@ -194,6 +195,16 @@ def posenc(x: torch.Tensor, L: int) -> torch.Tensor:
     out = torch.empty((M, D * (1 + 2 * L)), dtype=torch.float32, device=x.device)
     _check(lib.nerf_posenc_fwd(_dev(x, "x"), M, D, L, _dev(out, "out"), _stream()), "nerf_posenc_fwd")
     return out
+
+
+def posenc_bwd(x: torch.Tensor, grad_out: torch.Tensor, L: int) -> torch.Tensor:
+    M, D = x.shape
+    if grad_out.shape != (M, D * (1 + 2 * L)):
+        raise ValueError("posenc_bwd: grad_out must be [M, D*(1+2L)]")
+    dx = torch.empty_like(x)
+    _check(lib.nerf_posenc_bwd(_dev(x, "x"), _dev(grad_out, "grad_out"), M, D, L, _dev(dx, "dx"), _stream()),
+           "nerf_posenc_bwd")
+    return dx
 
 
 # --------------------------------------------------------------------------- compositing

@@ -94,12 +94,13 @@ class _FusedMLP(nn.Module):
         if not points.is_cuda:
             raise RuntimeError("this build has no CPU path: move the model and its inputs to the HIP device "
                                "(model.to('cuda'))")
-        if points.requires_grad or rays_d.requires_grad:
-            raise NotImplementedError("gradients with respect to points/directions are not provided "
-                                      "(the reference's callers never request them)")
         if points.dim() != 2 or points.shape[1] != 3 or rays_d.shape != points.shape:
             raise ValueError("points and rays_d must both be [M,3]")
-        if not self.fused_supported():
+        inputs_need_grad = torch.is_grad_enabled() and (points.requires_grad or rays_d.requires_grad)
+        if inputs_need_grad or not self.fused_supported():
+            # The fused kernels produce parameter gradients only (the reference's callers never ask for more).
+            # Gradients with respect to points / directions, which the reference's forward also supports, come
+            # from the layer-wise kernels: every dense layer and the encoding have an input gradient there.
             return self._layerwise(_f32c(points), _f32c(rays_d))
         params = self.ordered_parameters()
         train = wants_grad(params)

@@ -2,7 +2,7 @@
 formulas and shape-only fake implementations, so that the dispatcher, torch.compile and opcheck see
 them; no arithmetic happens here.  Operators:
 
-    nerf::posenc(x, L)                                   nerf/encoding.py:4-20
+    nerf::posenc(x, L)                                   nerf/encoding.py:4-20 (+ nerf::posenc_backward)
     nerf::composite(colors, densities, deltas, white)    nerf/rendering.py:125-153 (+ nerf::composite_backward)
     nerf::mlp(model, packed, points, dirs, params, ...)  nerf/models.py:62-75 / :185-203 (+ nerf::mlp_backward)
     nerf::render(model, packed, rays_o, rays_d, t, ...)  one ray chunk of nerf/rendering.py:191-223: sample ->
@@ -144,6 +144,30 @@ def posenc_op(x: Tensor, L: int) -> Tensor:
 @posenc_op.register_fake
 def _(x, L):
     return x.new_empty((x.shape[0], x.shape[1] * (1 + 2 * L)))
+
+
+@custom_op("nerf::posenc_backward", mutates_args=())
+def posenc_backward_op(x: Tensor, grad_out: Tensor, L: int) -> Tensor:
+    return _hip.posenc_bwd(_f32c(x), _f32c(grad_out), int(L))
+
+
+@posenc_backward_op.register_fake
+def _(x, grad_out, L):
+    return torch.empty_like(x, memory_format=torch.contiguous_format)
+
+
+def _posenc_setup(ctx, inputs, output):
+    x, L = inputs
+    ctx.save_for_backward(x)
+    ctx.L = int(L)
+
+
+def _posenc_backward(ctx, grad_out):
+    (x,) = ctx.saved_tensors
+    return posenc_backward_op(x, grad_out, ctx.L), None
+
+
+posenc_op.register_autograd(_posenc_backward, setup_context=_posenc_setup)
 
 
 # ---------------------------------------------------------------------------------------- composite

@@ -41,6 +41,7 @@ def test_opcheck_posenc():
     x = torch.rand(100, 3, device=DEV) * 2 - 1
     torch.library.opcheck(torch.ops.nerf.posenc.default, (x, 10))
     torch.library.opcheck(torch.ops.nerf.posenc.default, (x[:, :2].contiguous(), 4))
+    torch.library.opcheck(torch.ops.nerf.posenc.default, (x.clone().requires_grad_(True), 4))
 
 
 def test_opcheck_composite():

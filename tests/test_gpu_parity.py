@@ -837,3 +837,53 @@ def test_render_nerf_no_rays():
     model, _ = make_model("nerf")
     out = render_nerf(model, torch.zeros(0, 3), torch.zeros(0, 3), 2.0, 6.0, num_samples=16, device=DEV)
     assert out.shape == (0, 3)
+
+
+# ----------------------------------------------------------------------------- gradients wrt the inputs
+@pytest.mark.parametrize("D,L", [(3, 10), (3, 4), (2, 0), (4, 7)])
+def test_posenc_backward_vs_torch(D, L):
+    """positional_encoding is built from differentiable torch ops in the reference (encoding.py:15-20)."""
+    from nerf.encoding import positional_encoding
+    g = torch.Generator().manual_seed(400 + 10 * D + L)
+    x = torch.rand(777, D, generator=g) * 3 - 1.5
+    gout = torch.randn(777, D * (1 + 2 * L), generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    O.positional_encoding(xr, L).backward(gout.double())
+    xg = x.to(DEV).requires_grad_(True)
+    out = positional_encoding(xg, L)
+    assert out.requires_grad
+    out.backward(gout.to(DEV))
+    assert rel(xg.grad, xr.grad) < RTOL
+
+
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
+def test_model_input_gradients_vs_oracle(tag):
+    """Model.forward is differentiable in points and directions in the reference (models.py:62-75, :185-203);
+    here such calls take the layer-wise kernels.  Samples on a ReLU kink are dropped as elsewhere."""
+    model, params = make_model(tag)
+    M = 300
+    g = torch.Generator().manual_seed(77)
+    pts = torch.rand(M, 3, generator=g) * 2 - 1
+    dirs = torch.randn(M, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    gc, gd = torch.randn(M, 3, generator=g), torch.randn(M, generator=g) * 0.1
+    with torch.no_grad():
+        _, _, acts = oracle_fwd(tag)(params, pts, dirs, return_acts=True)
+    keep = O.relu_kink_distance(acts) > 3e-6
+    pts, dirs, gc, gd = pts[keep].contiguous(), dirs[keep].contiguous(), gc[keep].contiguous(), gd[keep].contiguous()
+    pr, dr = pts.clone().requires_grad_(True), dirs.clone().requires_grad_(True)
+    for p in params.values():
+        p.requires_grad_(True)
+    c_ref, d_ref = oracle_fwd(tag)(params, pr, dr)
+    ((c_ref * gc).sum() + (d_ref * gd).sum()).backward()
+    pg, dg = pts.to(DEV).requires_grad_(True), dirs.to(DEV).requires_grad_(True)
+    colors, dens = model(pg, dg)
+    ((colors * gc.to(DEV)).sum() + (dens * gd.to(DEV)).sum()).backward()
+    assert rel(colors, c_ref) < RTOL and rel(dens, d_ref) < RTOL
+    assert rel(pg.grad, pr.grad) < RTOL, rel(pg.grad, pr.grad)
+    assert rel(dg.grad, dr.grad) < RTOL, rel(dg.grad, dr.grad)
+    for (n, p), q in zip(model.named_parameters(), params.values()):
+        assert rel(p.grad, q.grad) < RTOL, (n, rel(p.grad, q.grad))
+    # without input gradients the same call takes the fused kernel and agrees with the layer-wise result
+    c2, d2 = model(pts.to(DEV), dirs.to(DEV))
+    assert rel(c2, colors) < RTOL and rel(d2, dens) < RTOL
