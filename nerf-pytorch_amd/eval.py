@@ -45,6 +45,14 @@ def write_png(path: str, frame: np.ndarray) -> None:
         Image.fromarray(frame).save(path)
 
 
+def poses_for_rank(n_poses: int, rank: int, world: int) -> range:
+    """Pose indices rendered by `rank` of `world` processes (one per GPU): round-robin, every pose exactly once,
+    no exchange between ranks -- each writes its own frames."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return range(rank, n_poses, world)
+
+
 def quantise(rgb: torch.Tensor) -> torch.Tensor:
     """(clip(rgb, 0, 1) * 255) truncated to uint8, on the device (eval.py:149-150)."""
     return (rgb.clamp(0.0, 1.0) * 255).to(torch.uint8)
@@ -105,7 +113,7 @@ def main(argv=None):
         focal = focal * args.resolution / W
         H = W = args.resolution
     angles = np.linspace(-180, 180, n_poses + 1)[:-1]
-    for i in range(rank, n_poses, world):
+    for i in poses_for_rank(n_poses, rank, world):
         c2w = torch.from_numpy(pose_spherical(float(angles[i]), -30.0, 4.0))[None].to(device)
         ro, rd = compute_rays_device(H, W, c2w, focal)
         with torch.no_grad():

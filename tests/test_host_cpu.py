@@ -156,3 +156,18 @@ def test_flat_bucket_slices_for_several_networks():
     flat.grad.fill_(1.0)
     flat.zero_grad()
     assert float(flat.grad.abs().max()) == 0.0 and len(flat.fused) == 2
+
+
+def test_eval_pose_sharding_covers_every_pose_once():
+    """Inference over N GPUs shards the camera path by pose with no collective: 200 poses over 8 ranks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("eval_driver", os.path.join(ROOT, "nerf-pytorch_amd", "eval.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    for n, world in ((200, 8), (40, 3), (5, 8), (0, 2)):
+        seen = sorted(i for r in range(world) for i in ev.poses_for_rank(n, r, world))
+        assert seen == list(range(n))
+        sizes = [len(ev.poses_for_rank(n, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        ev.poses_for_rank(10, 3, 3)
