@@ -343,24 +343,33 @@ def main():
             for name, k in kernels.items():
                 if name.split("@")[0] != "mlp_fwd_train":
                     k["concurrent"] = True          # bracket includes the other stream's kernels
-        # the roofline object describes ONE kernel of the timed region that ran alone on the device: the fused
-        # forward (the slowest single launch of the step; the weight-gradient entry is a launch group)
-        single = [k for k in kernels if not k.startswith("mlp_bwd_weights") and not kernels[k].get("concurrent")]
-        dom = max(single, key=lambda k: kernels[k]["ms_per_launch"]) if single else None
+        # The roofline object describes ONE kernel over all its launches of the timed region (what a rocprofv3
+        # --kernel-trace --stats average of the same command shows): the fused forward, which runs alone on the
+        # device (its coarse launch on the side stream, its fine launch on the main one) and is the slowest
+        # single kernel of the step; the weight-gradient entry is a launch group.
+        alone = {}
+        for name, k in kernels.items():
+            if k.get("concurrent") or name.startswith("mlp_bwd_weights"):
+                continue
+            m = alone.setdefault(name.split("@")[0], {"n": 0.0, "ms": 0.0, "flop": 0.0, "per_sample": k["flop_per_sample"]})
+            m["n"] += k["launches_per_step"]
+            m["ms"] += k["ms_per_step"]
+            m["flop"] += k["flop_per_launch"] * k["launches_per_step"]
+        dom = max(alone, key=lambda b: alone[b]["ms"]) if alone else None
         roof = None
         if dom:
-            ach = kernels[dom]["tflops"]
-            per_sample = kernels[dom]["flop_per_sample"]
-            samples_per_launch = kernels[dom]["flop_per_launch"] / per_sample
-            tb, tb_files = pmc_traffic_per_sample(args.model, dom.split("@")[0])
+            m = alone[dom]
+            ach = m["flop"] / m["ms"] / 1e9
+            samples_per_launch = m["flop"] / m["n"] / m["per_sample"]
+            tb, tb_files = pmc_traffic_per_sample(args.model, dom)
             peak = PEAK_BF16_MFMA_TFLOPS if dom.endswith("bf16") else PEAK_F32_MFMA_TFLOPS
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                     "frac": ach / peak, "traffic": tb * samples_per_launch if tb else None,
                     "traffic_unit": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) per sample of the rocprofv3 --pmc "
-                                    "passes in traffic_source x samples of this launch",
-                    "traffic_source": tb_files,
-                    "ms_per_launch": kernels[dom]["ms_per_launch"], "flop_per_launch": kernels[dom]["flop_per_launch"],
-                    "flop_per_sample": per_sample, "samples_per_launch": samples_per_launch}
+                                    "passes in traffic_source x mean samples per launch",
+                    "traffic_source": tb_files, "launches_per_step": m["n"],
+                    "ms_per_launch": m["ms"] / m["n"], "flop_per_launch": m["flop"] / m["n"],
+                    "flop_per_sample": m["per_sample"], "samples_per_launch": samples_per_launch}
         total_flop = sum(k["flop_per_launch"] * k["launches_per_step"] for k in kernels.values())
         ms_step = elapsed / args.steps * 1e3
         res = {
