@@ -162,7 +162,13 @@ __device__ __forceinline__ int acc_row(int mi, int g, int lane) { return 32 * mi
 // Forward epilogue: activation, write the tile back to LDS as the next layer's input.
 // The post-activation tile itself goes to the workspace later, from LDS, inside the next MFMA loop
 // that reads it (mma_layer's COPY_COLS); for sine layers (training) the derivative cos(z) has no LDS
-// home and is stored from the accumulator layout: gcos = row 0 of this tile, [TR][ldg].
+// home and is stored from the accumulator registers: gcos = this tile's [TR][ldg] region of the workspace.
+//   NT == 1 (the 128-wide rgb sine layer, whose derivative the head gradient reads by rows): row-major, one
+//           4-byte store per element;
+//   NT == 2 (hidden sine layers): ACCUMULATOR ORDER -- the region holds, for every group of four accumulator
+//           registers q = (mi*NT + ni)*4 + g/4, one 16-byte piece per thread at float offset (q*256 + tid)*4,
+//           so a thread stores (and the data-gradient kernel, whose tiles have the same register map, loads)
+//           16 fully coalesced 16-byte pieces instead of 64 strided 4-byte ones.
 // relu_mask (may be NULL): receives this lane's MT*32 (v > 0) bits, accumulator order.
 template <int NT, int ACT, bool STORE_COS>
 __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], int ncol0, int lane,
@@ -174,13 +180,15 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], 
     int cos_voff = 0;
     if constexpr (STORE_COS && ACT == ACT_SIN) {
         cos_rsrc = make_rsrc(gcos, (unsigned)(TR * ldg * 4));
-        cos_voff = (4 * (lane >> 5) * ldg + ncol0 + (lane & 31)) * 4;
+        if constexpr (NT == 1) cos_voff = (4 * (lane >> 5) * ldg + ncol0 + (lane & 31)) * 4;
+        else cos_voff = ((ncol0 / (32 * NT)) * 64 + lane) * 16;   // tid * 16 bytes
     }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int col = ncol0 + 32 * ni + (lane & 31);
+            f32x4 cpiece = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int row = acc_row(mi, g, lane);
@@ -200,9 +208,23 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], 
                     v = s;
                 }
                 act[row * LDA + col] = v;
-                if constexpr (STORE_COS && ACT == ACT_SIN)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), cos_rsrc, cos_voff,
-                                                          ((32 * mi + (g & 3) + 8 * (g >> 2)) * ldg + 32 * ni) * 4, 0);
+                if constexpr (STORE_COS && ACT == ACT_SIN) {
+                    if constexpr (NT == 1) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), cos_rsrc, cos_voff,
+                                                              ((32 * mi + (g & 3) + 8 * (g >> 2)) * ldg + 32 * ni) * 4, 0);
+                    } else {
+                        cpiece[g & 3] = c;
+                        if ((g & 3) == 3)
+                            // The piece offset goes into the VGPR offset and the scalar offset stays the constant 0 on
+                            // purpose.  With the offset in an SGPR, hipcc lets a VALU instruction overwrite the four data
+                            // registers in the very next slot (its hazard model exempts stores with a register soffset), and
+                            // on gfx950 the store then writes a mix of old and new values for some 4-lane groups once several
+                            // workgroups keep the memory pipeline busy (seen as run-to-run differences of the derivative
+                            // tiles from 1024 tiles on).  With an immediate soffset the compiler inserts the wait state.
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, cpiece), cos_rsrc,
+                                                                   cos_voff + ((mi * NT + ni) * 4 + (g >> 2)) * 256 * 16, 0, 2);
+                    }
+                }
             }
         }
     if constexpr (ACT == ACT_RELU && NT == 2) {
@@ -236,6 +258,12 @@ __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[MT][NT], 
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                              h_rsrc, h_voff, ((32 * mi + (g & 3) + 8 * (g >> 2)) * ldg + 32 * ni) * 4, 0));
     };
+    // MASK 2: the stored derivative tile is in accumulator order (see fwd_epilogue): 16-byte pieces
+    const int d_voff = ((ncol0 / (32 * NT)) * 64 + lane) * 16;
+    auto stored4 = [&](int mi, int ni, int g4) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, d_voff,
+                                                                               ((mi * NT + ni) * 4 + g4) * 256 * 16, 0));
+    };
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -243,13 +271,19 @@ __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[MT][NT], 
             const int col = ncol0 + 32 * ni + (lane & 31);
             float sw = 0.f;
             if constexpr (RANK1) sw = sigw[col];
+            f32x4 dpiece[4];
+            if constexpr (MASK == 2) {
+                static_assert(MASK != 2 || NT == 2, "accumulator-order derivative tiles exist for the 256-wide layers");
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) dpiece[g4] = stored4(mi, ni, g4);
+            }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int row = acc_row(mi, g, lane);
                 float v = acc[mi][ni][g];
                 if constexpr (RANK1) v = fmaf(dsig_lds[row], sw, v);
                 if constexpr (MASK == 1) v = stored(mi, ni, g) > 0.0f ? v : 0.0f;
-                if constexpr (MASK == 2) v = v * stored(mi, ni, g);
+                if constexpr (MASK == 2) v = v * dpiece[g >> 2][g & 3];
                 if constexpr (MASK == 3) {
                     const int bit = (mi * NT + ni) * 16 + g;
                     v = (((bit < 32 ? blo : bhi) >> (bit & 31)) & 1u) ? v : 0.0f;

@@ -459,7 +459,13 @@ __global__ __launch_bounds__(256, WG_PER_CU) void siren_fwd_kernel(FwdArgs a) {
             float sn, cs;
             nerf_sincosf(mul_rn(30.0f, z), &sn, &cs);
             act[s * LDA + tid] = sn;
-            if constexpr (TRAIN) gc[(size_t)s * H + tid] = 30.0f * cs;
+            if constexpr (TRAIN) {
+                // the derivative tile in the accumulator order the data-gradient kernel reads (fwd_epilogue):
+                // element (row s, column tid) is register g of lane (tid & 31) + 32*h of wave tid / 64
+                const int mi = s >> 5, rr = s & 31, hh = (rr >> 2) & 1, g = (rr & 3) + 4 * (rr >> 3);
+                const int owner = (tid >> 6) * 64 + (tid & 31) + 32 * hh, ni = (tid >> 5) & 1;
+                gc[(((mi * 2 + ni) * 4 + (g >> 2)) * 256 + owner) * 4 + (g & 3)] = 30.0f * cs;
+            }
         }
     }
     __syncthreads();

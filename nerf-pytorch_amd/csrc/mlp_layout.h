@@ -106,6 +106,8 @@ constexpr size_t d_img(int layer) { return D_L7 + (size_t)(7 - layer) * img(H, H
 
 // forward workspace per sample: xn [4] | de [32] | h0..h7 [8][256] | c0..c7 [8][256] (w0*cos) |
 // f [256] | g [128] | cg [128] | sraw [1]
+// c0..c7 are not row-major: each tile's region of a layer holds the derivative in the accumulator order of
+// the tile kernels (16-byte pieces per thread, see fwd_epilogue); only the data-gradient kernel reads them.
 constexpr size_t WS_X = 0, WS_DE = 4, WS_H = 36, WS_C = WS_H + 8 * H, WS_F = WS_C + 8 * H, WS_G = WS_F + H,
                  WS_CG = WS_G + HH, WS_SRAW = WS_CG + HH;
 constexpr size_t WS_PER_SAMPLE = WS_SRAW + 1;
