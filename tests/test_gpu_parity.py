@@ -193,11 +193,12 @@ def test_model_golden_forward_backward(golden, tag):
     ((colors * T(z["gc"]).to(DEV)).sum() + (dens * T(z["gd"]).to(DEV)).sum()).backward()
     for n, p in model.named_parameters():
         gn = float(z["gnorm." + n])
-        assert abs(float(p.grad.norm()) - gn) <= 2 * RTOL * gn, n
+        assert abs(float(p.grad.norm()) - gn) <= RTOL * gn, n
         f = p.grad.reshape(-1)
         step = max(1, f.numel() // 97)
         sub = f[::step][:97].cpu().numpy()
-        assert np.abs(sub - z["gsub." + n]).max() <= 50 * RTOL * gn / math.sqrt(f.numel()) + 1e-9, n
+        # element by element: within 3e-5 of the tensor's rms entry (measured: 0.8e-5; tests/diag/g4_ratio.py)
+        assert np.abs(sub - z["gsub." + n]).max() <= 3 * RTOL * gn / math.sqrt(f.numel()) + 1e-9, n
 
 
 @pytest.mark.parametrize("tag", ["nerf", "siren"])
@@ -323,10 +324,11 @@ def test_render_generic_module_path():
 def test_adam_trajectory_golden(golden, tag, optim):
     """Five optimizer steps as train.py:166-183 runs them; torch.optim.Adam + LambdaLR on the
     drop-in modules, and the fused flat Adam kernel.  Tolerance on the loss: 1e-5 relative at
-    step 0 (no update yet), 1e-4 after one update, 2e-3 later: Adam's g/sqrt(v) turns last-bit
-    differences of near-zero gradient entries into O(lr) parameter steps, and at lr 5e-4 these
-    five steps are far from converged (the loss moves by 2x per step), so the difference grows
-    geometrically.  A wrong bias correction, schedule or update rule is off by >1e-2."""
+    step 0 (no update yet), 2e-5 after one update, then 1e-4, 6e-4, 1e-3: Adam's g/sqrt(v) turns
+    last-bit differences of near-zero gradient entries into O(lr) parameter steps, and at lr 5e-4
+    these five steps are far from converged (the loss moves by 2x per step), so the difference grows
+    geometrically (measured, tests/diag/adam_traj.py: 0, 4e-6, 1.4e-5, 1.4e-4, 2.1e-4 for NeRF, below
+    3e-5 throughout for Siren).  A wrong bias correction, schedule or update rule is off by >1e-2."""
     from nerf import parallel
     from nerf.rendering import render_nerf
     z = golden(f"g7_{tag}.npz")
@@ -352,10 +354,10 @@ def test_adam_trajectory_golden(golden, tag, optim):
         opt.step()
         if optim == "torch":
             sched.step()
-        tol = (1e-5, 1e-4, 2e-3, 2e-3, 2e-3)[it]
+        tol = (1e-5, 2e-5, 1e-4, 6e-4, 1e-3)[it]
         assert abs(float(loss.detach()) - z["losses"][it]) <= tol * z["losses"][it], (it, float(loss.detach()))
     for n, p in model.named_parameters():
-        assert abs(float(p.detach().norm()) - float(z["pnorm." + n])) <= 1e-3 * float(z["pnorm." + n]) + 1e-7, n
+        assert abs(float(p.detach().norm()) - float(z["pnorm." + n])) <= 1e-4 * float(z["pnorm." + n]) + 1e-7, n
 
 
 def test_fused_adam_matches_torch_adam(hip):
