@@ -65,6 +65,9 @@ def main():
         ("weights_to_cdf B=64", lambda: _hip.weights_to_cdf(w), R * (64 * 4 + 65 * 4)),
         ("sample_pdf B=64 N=128", lambda: _hip.sample_pdf(bins, cdf, uu), R * (2 * 65 * 4 + 128 * 4 + 128 * 8)),
         ("merge_samples 64+128", lambda: _hip.merge_samples(tc, tf), R * (128 * 4 + 2 * 192 * 4)),
+        # the three steps above in one launch, as the hierarchical renderer chains them: reads the coarse weights and the
+        # draws, writes the merged depths and their differences
+        ("resample 64+128 (cdf + draws + merge, fused)", lambda: _hip.resample(w, tc, uu), R * (64 * 4 + 128 * 4 + 2 * 192 * 4)),
     ]
     for name, fn, nbytes in cases:
         sec = timeit(fn, args.iters)

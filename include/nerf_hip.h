@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 7
+#define NERF_ABI_VERSION 8
 
 #define NERF_OK 0
 #define NERF_E_ARG (-1)      /* bad shape / size / unsupported configuration */
@@ -212,6 +212,14 @@ int nerf_merge_samples(const float* t_coarse, const float* t_fine, int64_t R, in
                        float* deltas, void* stream);
 int nerf_sample_pdf(const float* bins, const float* cdf, const float* u, int64_t R, int B, int N,
                     float* samples, int32_t* idx, void* stream);
+
+/* The three steps above as they are chained between a coarse and a fine pass, in one launch (one ray per
+ * wavefront; CDF, bin edges and fine depths stay in LDS): weights [R,Sc] = the coarse pass's compositing weights,
+ * of which the interior ones weights[:,1:Sc-1] form the PDF over the Sc-1 mid-points of t_coarse [Sc]; u [R,Sf] ->
+ * t_all, deltas [R,Sc+Sf]; optional outputs (NULL to skip) t_fine [R,Sf], idx [R,Sf].  Bitwise the results of
+ * nerf_weights_to_cdf -> nerf_sample_pdf -> nerf_merge_samples.  Sc >= 3, Sc+Sf <= 1024. */
+int nerf_resample(const float* weights, const float* t_coarse, const float* u, int64_t R, int Sc, int Sf,
+                  float* t_all, float* deltas, float* t_fine, int32_t* idx, void* stream);
 
 #ifdef __cplusplus
 }

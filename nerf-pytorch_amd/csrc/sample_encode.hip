@@ -207,12 +207,8 @@ extern "C" int nerf_posenc_bwd(const float* x, const float* grad_out, int64_t M,
 //   comparison result, hence bit-exact for an identical CDF and identical draws.
 // One ray per wavefront.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void weights_to_cdf_kernel(const float* __restrict__ w, int64_t R, int B,
-                                                            float* __restrict__ cdf) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
-    if (r >= R) return;  // no block-wide barrier below: waves are independent
-    const float* wr = w + r * B;
+// CDF of one ray by one wave: wr [B] weights -> cr [B+1] (global or LDS)
+__device__ __forceinline__ void cdf_row(const float* __restrict__ wr, int B, float* cr, int lane) {
     float part = 0.f;
     for (int i = lane; i < B; i += 64) part += wr[i] + 1e-5f;
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
@@ -229,13 +225,20 @@ __global__ __launch_bounds__(256) void weights_to_cdf_kernel(const float* __rest
         if (lane >= off) inc += o;
     }
     float acc = inc - run;
-    float* cr = cdf + r * (B + 1);
     if (lane == 0) cr[0] = 0.f;
     for (int i = 0; i < per; ++i)
         if (b0 + i < B) {
             acc += (wr[b0 + i] + 1e-5f) / tot;
             cr[b0 + i + 1] = acc;
         }
+}
+
+__global__ __launch_bounds__(256) void weights_to_cdf_kernel(const float* __restrict__ w, int64_t R, int B,
+                                                            float* __restrict__ cdf) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    if (r >= R) return;  // no block-wide barrier below: waves are independent
+    cdf_row(w + r * B, B, cdf + r * (B + 1), lane);
 }
 
 extern "C" int nerf_weights_to_cdf(const float* weights, int64_t R, int B, float* cdf, void* stream) {
@@ -247,16 +250,9 @@ extern "C" int nerf_weights_to_cdf(const float* weights, int64_t R, int B, float
     return nerf_check_launch("nerf_weights_to_cdf");
 }
 
-__global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ bins, const float* __restrict__ cdf,
-                                                        const float* __restrict__ u, int64_t R, int B, int N,
-                                                        float* __restrict__ samples, int32_t* __restrict__ idx_out) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= R * N) return;
-    const int64_t r = e / N;
-    const float* c = cdf + r * (B + 1);
-    const float* bn = bins + r * (B + 1);
-    const float uu = u[e];
-    int lo = 0, hi = B + 1;  // first index with cdf[idx] > uu  (searchsorted right=True)
+// one inverse-CDF draw: c, bn [B+1] (global or LDS) -> sample; *idx = searchsorted(c, uu, right=True)
+__device__ __forceinline__ float pdf_sample(const float* c, const float* bn, int B, float uu, int* idx) {
+    int lo = 0, hi = B + 1;  // first index with cdf[idx] > uu
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (c[mid] <= uu) lo = mid + 1; else hi = mid;
@@ -266,7 +262,18 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
     float den = sub_rn(c1, c0);
     if (den < 1e-5f) den = 1.f;
     const float tt = div_rn(sub_rn(uu, c0), den);
-    samples[e] = add_rn(bn[below], mul_rn(tt, sub_rn(bn[above], bn[below])));
+    *idx = lo;
+    return add_rn(bn[below], mul_rn(tt, sub_rn(bn[above], bn[below])));
+}
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ bins, const float* __restrict__ cdf,
+                                                        const float* __restrict__ u, int64_t R, int B, int N,
+                                                        float* __restrict__ samples, int32_t* __restrict__ idx_out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * N) return;
+    const int64_t r = e / N;
+    int lo;
+    samples[e] = pdf_sample(cdf + r * (B + 1), bins + r * (B + 1), B, u[e], &lo);
     idx_out[e] = lo;
 }
 
@@ -337,20 +344,8 @@ extern "C" int nerf_compute_rays(const float* c2w, int64_t N, int H, int W, doub
 // carried out in program order, so the stages are separated by wave-level scheduling barriers only.
 // ---------------------------------------------------------------------------------------
 #define MERGE_MAX 1024
-__global__ __launch_bounds__(256) void merge_samples_kernel(const float* __restrict__ tc, const float* __restrict__ tf,
-                                                           int64_t R, int Sc, int Sf, int N, float* __restrict__ t_all,
-                                                           float* __restrict__ deltas) {
-    extern __shared__ float merge_lds[];   // per wave: fine [N] | coarse [Sc] | union [Sc+Sf]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t rr = r < R ? r : R - 1;  // out-of-range waves redo the last ray and store nothing
-    const int S = Sc + Sf;
-    float* b = merge_lds + (size_t)wv * (N + Sc + S);
-    float* c = b + N;
-    float* o = c + Sc;
-    for (int i = lane; i < N; i += 64) b[i] = i < Sf ? tf[rr * Sf + i] : INFINITY;
-    for (int i = lane; i < Sc; i += 64) c[i] = tc[i];
-    __builtin_amdgcn_wave_barrier();
+// sorts b [N] (the ray's fine depths padded with +inf) and merges it with the ascending c [Sc] into o [Sc+Sf]
+__device__ __forceinline__ void merge_row(float* b, const float* c, float* o, int Sc, int Sf, int N, int lane) {
     for (int k = 2; k <= N; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = lane; i < N; i += 64) {
@@ -382,6 +377,67 @@ __global__ __launch_bounds__(256) void merge_samples_kernel(const float* __restr
         o[j + lo] = v;
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void merge_samples_kernel(const float* __restrict__ tc, const float* __restrict__ tf,
+                                                           int64_t R, int Sc, int Sf, int N, float* __restrict__ t_all,
+                                                           float* __restrict__ deltas) {
+    extern __shared__ float merge_lds[];   // per wave: fine [N] | coarse [Sc] | union [Sc+Sf]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t rr = r < R ? r : R - 1;  // out-of-range waves redo the last ray and store nothing
+    const int S = Sc + Sf;
+    float* b = merge_lds + (size_t)wv * (N + Sc + S);
+    float* c = b + N;
+    float* o = c + Sc;
+    for (int i = lane; i < N; i += 64) b[i] = i < Sf ? tf[rr * Sf + i] : INFINITY;
+    for (int i = lane; i < Sc; i += 64) c[i] = tc[i];
+    __builtin_amdgcn_wave_barrier();
+    merge_row(b, c, o, Sc, Sf, N, lane);
+    if (r < R)
+        for (int i = lane; i < S; i += 64) {
+            t_all[r * S + i] = o[i];
+            deltas[r * S + i] = (i + 1 < S) ? sub_rn(o[i + 1], o[i]) : 1e10f;
+        }
+}
+
+// Fused re-sampling of one ray per wave: CDF of the interior coarse weights over the mid-points of the coarse
+// depths, Nf inverse-CDF draws, sorted union with the coarse depths, successive differences -- the chain
+// weights_to_cdf -> sample_pdf -> merge_samples in ONE launch, built from the same device functions (bitwise
+// the same results), with CDF, mid-points and fine depths kept in LDS instead of going through HBM.
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ w, const float* __restrict__ tc,
+                                                      const float* __restrict__ u, int64_t R, int Sc, int Sf, int N,
+                                                      float* __restrict__ t_all, float* __restrict__ deltas,
+                                                      float* __restrict__ t_fine, int32_t* __restrict__ idx_out) {
+    extern __shared__ float merge_lds[];   // per wave: fine [N] | coarse [Sc] | union [Sc+Sf] | cdf [Sc-1] | mid [Sc-1]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t rr = r < R ? r : R - 1;  // out-of-range waves redo the last ray and store nothing
+    const int S = Sc + Sf, B = Sc - 2;
+    float* b = merge_lds + (size_t)wv * (N + Sc + S + 2 * (Sc - 1));
+    float* c = b + N;
+    float* o = c + Sc;
+    float* cdf = o + S;
+    float* mid = cdf + (Sc - 1);
+    for (int i = lane; i < Sc; i += 64) c[i] = tc[i];
+    cdf_row(w + rr * Sc + 1, B, cdf, lane);                      // interior weights w[1 .. Sc-2]
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < Sc - 1; i += 64) mid[i] = mul_rn(0.5f, add_rn(c[i + 1], c[i]));
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < N; i += 64) {
+        float v = INFINITY;
+        if (i < Sf) {
+            int lo;
+            v = pdf_sample(cdf, mid, B, u[rr * Sf + i], &lo);
+            if (r < R) {
+                if (t_fine) t_fine[r * Sf + i] = v;
+                if (idx_out) idx_out[r * Sf + i] = lo;
+            }
+        }
+        b[i] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    merge_row(b, c, o, Sc, Sf, N, lane);
     if (r < R)
         for (int i = lane; i < S; i += 64) {
             t_all[r * S + i] = o[i];
@@ -404,4 +460,23 @@ extern "C" int nerf_merge_samples(const float* t_coarse, const float* t_fine, in
     merge_samples_kernel<<<(unsigned)ceil_div64(R, 4), 256, lds, (hipStream_t)stream>>>(t_coarse, t_fine, R, Sc, Sf, N,
                                                                                        t_all, deltas);
     return nerf_check_launch("nerf_merge_samples");
+}
+
+extern "C" int nerf_resample(const float* weights, const float* t_coarse, const float* u, int64_t R, int Sc, int Sf,
+                             float* t_all, float* deltas, float* t_fine, int32_t* idx, void* stream) {
+    NERF_REQUIRE(R >= 0 && Sc >= 3 && Sf >= 1 && Sc + Sf <= MERGE_MAX, "nerf_resample: bad R=%lld Sc=%d Sf=%d (Sc >= 3, Sc+Sf <= %d)",
+                 (long long)R, Sc, Sf, MERGE_MAX);
+    if (R == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(weights);
+    NERF_REQUIRE_PTR(t_coarse);
+    NERF_REQUIRE_PTR(u);
+    NERF_REQUIRE_PTR(t_all);
+    NERF_REQUIRE_PTR(deltas);
+    int N = 2;   // bitonic length: the fine depths padded to a power of two
+    while (N < Sf) N <<= 1;
+    const size_t lds = 4 * (size_t)(N + 2 * Sc + Sf + 2 * (Sc - 1)) * sizeof(float);   // at most 4 * 5118 * 4 = 80 KiB
+    if (int rc = nerf_set_lds(resample_kernel, (int)lds)) return rc;
+    resample_kernel<<<(unsigned)ceil_div64(R, 4), 256, lds, (hipStream_t)stream>>>(weights, t_coarse, u, R, Sc, Sf, N, t_all,
+                                                                                  deltas, t_fine, idx);
+    return nerf_check_launch("nerf_resample");
 }

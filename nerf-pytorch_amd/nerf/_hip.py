@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 MODEL_NERF = 0
 MODEL_SIREN = 1
 NUM_PARAM_TENSORS = 24
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -63,6 +63,7 @@ _SIGS = {
     "nerf_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_double, c_double, c_double, c_double, c_double, _P]),
     "nerf_weights_to_cdf": (c_int, [_P, c_int64, c_int, _P, _P]),
     "nerf_sample_pdf": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
+    "nerf_resample": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)
 for _name, (_res, _args) in _SIGS.items():
@@ -411,3 +412,20 @@ def sample_pdf(bins: torch.Tensor, cdf: torch.Tensor, u: torch.Tensor):
     _check(lib.nerf_sample_pdf(_dev(bins, "bins"), _dev(cdf, "cdf"), _dev(u, "u"), R, B1 - 1, N, _dev(samples, "samples"),
                                _dev(idx, "idx", torch.int32), _stream()), "nerf_sample_pdf")
     return samples, idx
+
+
+def resample(weights: torch.Tensor, t_coarse: torch.Tensor, u: torch.Tensor, want_fine: bool = False):
+    """Coarse weights [R,Sc], shared coarse depths [Sc], draws [R,Sf] -> (t_all, deltas) [R,Sc+Sf] (+ t_fine [R,Sf],
+    idx [R,Sf] with want_fine): CDF, inverse-CDF draws and sorted union in one launch."""
+    R, Sc = weights.shape
+    if t_coarse.shape != (Sc,) or u.dim() != 2 or u.shape[0] != R:
+        raise ValueError("resample: weights [R,Sc], t_coarse [Sc], u [R,Sf]")
+    Sf = u.shape[1]
+    t_all = torch.empty((R, Sc + Sf), dtype=torch.float32, device=weights.device)
+    deltas = torch.empty_like(t_all)
+    t_fine = torch.empty((R, Sf), dtype=torch.float32, device=weights.device) if want_fine else None
+    idx = torch.empty((R, Sf), dtype=torch.int32, device=weights.device) if want_fine else None
+    _check(lib.nerf_resample(_dev(weights, "weights"), _dev(t_coarse, "t_coarse"), _dev(u, "u"), R, Sc, Sf, _dev(t_all, "t_all"),
+                             _dev(deltas, "deltas"), _opt(t_fine, "t_fine"),
+                             None if idx is None else _dev(idx, "idx", torch.int32), _stream()), "nerf_resample")
+    return (t_all, deltas, t_fine, idx) if want_fine else (t_all, deltas)

@@ -195,11 +195,11 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
             rgb_c, w_c, _, _ = RenderFunction.apply(coarse.model_id, wc, o, d, t_c, deltas_c, float(near), float(far),
                                                     bool(white_background), True, tc_train, sink_c, *pc)
         with torch.no_grad():
-            t_mid = (0.5 * (t_c[1:] + t_c[:-1])).expand(R, -1).contiguous()          # [R, Nc-1] bin edges
-            cdf = _hip.weights_to_cdf(w_c[:, 1:-1].contiguous())                      # [R, Nc-1]
+            # PDF of the interior coarse weights over the mid-points of the coarse depths, num_fine inverse-CDF
+            # draws per ray, sorted union with the coarse depths: one launch (nerf_resample = nerf_weights_to_cdf
+            # -> nerf_sample_pdf -> nerf_merge_samples, bitwise)
             uf = torch.rand(R, num_fine, device=rays_o.device) if u_fine is None else _f32c(u_fine[ci].to(rays_o.device))
-            t_f, _ = _hip.sample_pdf(t_mid, cdf, uf)
-            t_all, deltas_all = _hip.merge_samples(t_c, t_f)
+            t_all, deltas_all = _hip.resample(w_c.detach(), t_c, uf)
         res = RenderFunction.apply(fine.model_id, wf, o, d, t_all, deltas_all, float(near), float(far),
                                    bool(white_background), bool(return_extras), tf_train, sink_f, *pf)
         out_c.append(rgb_c)

@@ -889,3 +889,28 @@ def test_model_input_gradients_vs_oracle(tag):
     # without input gradients the same call takes the fused kernel and agrees with the layer-wise result
     c2, d2 = model(pts.to(DEV), dirs.to(DEV))
     assert rel(c2, colors) < RTOL and rel(d2, dens) < RTOL
+
+
+@pytest.mark.parametrize("R,Sc,Sf", [(257, 64, 128), (5, 3, 1), (33, 17, 100), (4, 512, 512), (130, 64, 192)])
+def test_fused_resample_equals_the_three_steps(hip, R, Sc, Sf):
+    """nerf_resample (one launch between the coarse and the fine pass) against nerf_weights_to_cdf ->
+    nerf_sample_pdf -> nerf_merge_samples on the same inputs: bit for bit, indices included."""
+    g = torch.Generator().manual_seed(R + Sc + Sf)
+    t_c = O.stratified_t(2.0, 6.0, Sc, torch.rand(Sc, generator=g)).to(DEV)
+    w = (torch.rand(R, Sc, generator=g) ** 4)
+    w[R // 2] = 0.0                                   # an empty ray: uniform PDF from the 1e-5 floor
+    u = torch.rand(R, Sf, generator=g)
+    u[0, 0] = 0.0
+    u[-1, -1] = 1.0 - 1e-7
+    w, u = w.to(DEV), u.to(DEV)
+    t_mid = (0.5 * (t_c[1:] + t_c[:-1])).expand(R, -1).contiguous()
+    cdf = hip.weights_to_cdf(w[:, 1:-1].contiguous())
+    t_f, idx = hip.sample_pdf(t_mid, cdf, u)
+    t_all, deltas = hip.merge_samples(t_c, t_f)
+    f_all, f_deltas, f_fine, f_idx = hip.resample(w, t_c, u, want_fine=True)
+    assert torch.equal(f_idx, idx) and torch.equal(f_fine, t_f)
+    assert torch.equal(f_all, t_all) and torch.equal(f_deltas, deltas)
+    g_all, g_deltas = hip.resample(w, t_c, u)
+    assert torch.equal(g_all, t_all) and torch.equal(g_deltas, deltas)
+    idx_ref = torch.searchsorted(cdf.cpu().contiguous(), u.cpu().contiguous(), right=True)
+    assert torch.equal(f_idx.cpu().long(), idx_ref)
