@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collects the profiles of one round on the GPU box (run from the repository root through gpurun):
-#   bash profiles/collect.sh r2
+#   bash profiles/collect.sh r2            (everything)
+#   bash profiles/collect.sh r2 modes      (only the bench lines of the other modes and the HBM-bound kernels)
 # writes gpurun_out/<tag>/prof/<tag>_*.csv|json|jsonl; copy what should be judged into profiles/.
 #   * rocprofv3 --kernel-trace --stats of the default bench command and of its other modes
 #   * separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ) of the single-pass workload, where every
@@ -8,6 +9,7 @@
 #   * bench.py lines of the other modes (builder-run, kept next to the profiles)
 set -u
 TAG=${1:-r2}
+ONLY=${2:-all}
 OUT=$PWD/gpurun_out/$TAG/prof
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -25,6 +27,19 @@ pmc() {     # name, counters...
         > /dev/null 2> "$OUT/pmc_$name.log" || return 1
     python3 profiles/summarize_pmc.py "$OUT/pmc_$name" > "$OUT/${TAG}_pmc_$name.csv"
 }
+modes() {
+    : > "$OUT/${TAG}_bench_modes.jsonl"
+    for args in "--sampling single" "--sampling single --model siren" "--model siren" "--mode infer" "--mode infer --sampling single" \
+                "--mode infer --precision bf16" "--mode infer --precision bf16 --rays 32768" "--mode infer --rays 640000 --steps 3 --warmup 1" \
+                "--rays 1024" "--rays 16384"; do
+        timeout -k 10 300 python3 bench.py $args --no-cpu-baseline >> "$OUT/${TAG}_bench_modes.jsonl" 2>> "$OUT/modes.err" || return 1
+    done
+    timeout -k 10 300 python3 bench_kernels.py > "$OUT/${TAG}_hbm_kernels.jsonl" 2> "$OUT/hbm.err"
+}
+if [ "$ONLY" = modes ]; then
+    modes && echo "modes collected in $OUT"
+    exit $?
+fi
 stats hier --steps 6 --warmup 2 &&
 stats single --steps 6 --warmup 2 --sampling single &&
 stats siren --steps 6 --warmup 2 --sampling single --model siren &&
@@ -32,13 +47,5 @@ pmc fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
 pmc write WRITE_SIZE &&
 pmc sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
 echo '{"samples_per_dispatch": 1048576, "command": "rocprofv3 --pmc <counters> -- python3 bench.py --sampling single --steps 3 --warmup 1 --no-cpu-baseline", "unit": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (profiles/summarize_pmc.py means)"}' > "$OUT/${TAG}_pmc_meta.json" &&
-{
-  : > "$OUT/${TAG}_bench_modes.jsonl"
-  for args in "--sampling single" "--sampling single --model siren" "--model siren" "--mode infer" "--mode infer --sampling single" \
-              "--mode infer --precision bf16" "--mode infer --precision bf16 --rays 32768" "--mode infer --rays 640000 --steps 3 --warmup 1" \
-              "--rays 1024" "--rays 16384"; do
-      timeout -k 10 300 python3 bench.py $args --no-cpu-baseline >> "$OUT/${TAG}_bench_modes.jsonl" 2>> "$OUT/modes.err" || exit 1
-  done
-} &&
-timeout -k 10 300 python3 bench_kernels.py > "$OUT/${TAG}_hbm_kernels.jsonl" 2> "$OUT/hbm.err" &&
+modes &&
 echo "profiles collected in $OUT"
