@@ -185,6 +185,8 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
             # the fine network's backward; in the forward direction the fine pass waits for it as before
             main, side = torch.cuda.current_stream(rays_o.device), ops.side_stream(rays_o.device)
             side.wait_stream(main)
+            for x in (o, d, t_c, deltas_c, wc):     # main-stream memory that side-stream kernels read, now and in backward
+                x.record_stream(side)
             with torch.cuda.stream(side):
                 rgb_c, w_c, _, _ = RenderFunction.apply(coarse.model_id, wc, o, d, t_c, deltas_c, float(near), float(far),
                                                         bool(white_background), True, tc_train, sink_c, *pc)
