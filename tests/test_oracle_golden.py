@@ -152,3 +152,55 @@ def test_compute_rays_and_pose():
     assert ro.shape == (64, 3) and rd.shape == (64, 3)
     np.testing.assert_allclose(np.linalg.norm(rd, axis=1), 1.0, rtol=1e-6)
     np.testing.assert_allclose(np.linalg.norm(ro, axis=1), 4.0, rtol=1e-6)
+
+
+def test_configuration_1_cpu_plumbing(tmp_path):
+    """The CPU-runnable configuration: a config_lego-style file at half resolution (400x400), 1024 rays per batch,
+    64 coarse + 128 fine samples -- config parsing, pinhole rays of one pose, a shuffled 1024-ray batch, one coarse + fine
+    render with both losses, gradients and an Adam step with the LambdaLR factor, all on the CPU restatement (the HIP path
+    needs a GPU; this is the plumbing around it)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "nerf-pytorch_amd"))
+    from nerf.data import BatchCursor
+    from nerf.loss import mse_to_psnr
+    from nerf.utils import parse_config
+    cfg_path = tmp_path / "config_half_res.txt"
+    cfg_path.write_text("dataset_path = ./datasets/lego   # not read here\nnum_random_rays = 1024\nchunk_size = 8192\n"
+                        "num_samples = 64\nnum_fine_samples = 128\nlearning_rate = 5e-4\nnear = 2.0\nfar = 6.0\n"
+                        "lr_decay = 150\nlr_decay_factor = 0.1\nlr_min = 1e-5\nmodel_type = nerf\n")
+    cfg = parse_config(str(cfg_path))
+    B, Nc, Nf = int(cfg["num_random_rays"]), int(cfg["num_samples"]), int(cfg["num_fine_samples"])
+    near, far, lr = float(cfg["near"]), float(cfg["far"]), float(cfg["learning_rate"])
+    assert (B, Nc, Nf, cfg["model_type"]) == (1024, 64, 128, "nerf")
+    H = W = 400
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    ro, rd = O.compute_rays_np(H, W, O.pose_spherical(30.0, -30.0, 4.0).astype(np.float32), focal)
+    assert ro.shape == (H * W, 3) and np.allclose(np.linalg.norm(rd, axis=1), 1.0, atol=1e-6)
+    idx = BatchCursor(H * W, "cpu", torch.Generator().manual_seed(42)).next(B)
+    o, d = torch.from_numpy(ro)[idx], torch.from_numpy(rd)[idx]
+    g = torch.Generator().manual_seed(1)
+    tgt = torch.rand(B, 3, generator=g)
+    pc = O.closed_form_params(O.nerf_param_shapes())
+    pf = {k: v.clone() for k, v in pc.items()}
+    for p in list(pc.values()) + list(pf.values()):
+        p.requires_grad_(True)
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    rc, rf, w_f, t_all = O.render_hierarchical(lambda x, v: O.nerf_forward(pc, x, v), lambda x, v: O.nerf_forward(pf, x, v),
+                                               o, d, near, far, Nc, Nf, torch.rand(Nc, generator=g),
+                                               torch.rand(B, Nf, generator=g))
+    assert rc.shape == (B, 3) and rf.shape == (B, 3) and t_all.shape == (B, Nc + Nf) and w_f.shape == (B, Nc + Nf)
+    assert bool((t_all[:, 1:] >= t_all[:, :-1]).all()) and float(t_all.min()) >= near and float(t_all.max()) <= far
+    loss = torch.nn.functional.mse_loss(rc, tgt) + torch.nn.functional.mse_loss(rf, tgt)
+    allp = list(pc.values()) + list(pf.values())
+    grads = torch.autograd.grad(loss, allp)
+    assert all(torch.isfinite(gr).all() for gr in grads) and sum(float(gr.abs().sum()) for gr in grads) > 0
+    factor = O.lr_lambda(0, lr, float(cfg["lr_decay"]), float(cfg["lr_decay_factor"]), float(cfg["lr_min"]))
+    assert factor == 1.0
+    before = float(allp[0].detach().norm())
+    with torch.no_grad():
+        for p, gr in zip(allp, grads):
+            O.adam_step(p, gr, torch.zeros_like(p), torch.zeros_like(p), 1, lr * factor)
+    assert float(allp[0].detach().norm()) != before
+    assert 0.0 < mse_to_psnr(float(torch.nn.functional.mse_loss(rf, tgt).detach())) < 60.0
