@@ -45,14 +45,17 @@ def main(argv=None):
     ap.add_argument('--resume', type=str, default=None)
     ap.add_argument('--optimizer', choices=['fused', 'torch'], default='fused')
     ap.add_argument('--max-iters', type=int, default=None, help='stop early (smoke runs)')
+    ap.add_argument('--dist-backend', choices=['nccl', 'gloo'], default='nccl',
+                    help='nccl = RCCL, one GPU per rank; gloo + --one-device rehearses the multi-rank path on one GPU')
+    ap.add_argument('--one-device', action='store_true', help='rehearsal only: every rank uses cuda:0')
     args = ap.parse_args(argv)
     cfg = parse_config(args.config)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(args.dist_backend)
     if not torch.cuda.is_available():
         raise RuntimeError("this build needs a HIP device (no CPU path)")
     device = torch.device("cuda", torch.cuda.current_device())
@@ -167,6 +170,8 @@ def main(argv=None):
             loss = sum(mse(p, tgt) for p in preds)
             loss.backward()
             loss = mse(preds[-1].detach(), tgt)   # what is logged: the loss of the image that is kept
+            if world > 1 and args.dist_backend == 'gloo':
+                torch.cuda.synchronize()    # rehearsal backend only: start the host-staged collective on an idle device
             if flat is not None:
                 flat.all_reduce_mean(scale_in_optimizer=True)   # 1/world rides in the Adam kernel's gradient scale
                 opt.lr = learning_rate * parallel.lr_lambda(step, learning_rate, lr_decay, lr_decay_factor, lr_min)
