@@ -97,7 +97,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_fwd_kernel(
     }
     float T = wave_excl_prod(prod, lane);
     float sr = 0.f, sg = 0.f, sb = 0.f, sw = 0.f, sd = 0.f;
-    float w[EPL];
+    float w[EPL], tv[EPL];
+    if (depth) {
+        if constexpr (VEC) {
+            const f32x4* tp = reinterpret_cast<const f32x4*>(tvals + lane * EPL);
+#pragma unroll
+            for (int q = 0; q < EPL / 4; ++q) {
+                const f32x4 v = tp[q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tv[4 * q + k] = v[k];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) tv[e] = (lane * EPL + e < S) ? tvals[lane * EPL + e] : 0.f;
+        }
+    }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         w[e] = T * alpha[e];
@@ -106,16 +120,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_fwd_kernel(
         sg += w[e] * col[e][1];
         sb += w[e] * col[e][2];
         sw += w[e];
-        if (depth) {
-            const int s = lane * EPL + e;
-            sd += w[e] * (s < S ? tvals[s] : 0.f);
-        }
+        if (depth) sd += w[e] * tv[e];
     }
     if (weights) {
+        if constexpr (VEC) {   // S == 64*EPL, EPL % 4 == 0: the lane's weights as 16-byte stores
+            f32x4* wp = reinterpret_cast<f32x4*>(weights + r * S + lane * EPL);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int s = lane * EPL + e;
-            if (s < S) weights[r * S + s] = w[e];
+            for (int q = 0; q < EPL / 4; ++q) wp[q] = f32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int s = lane * EPL + e;
+                if (s < S) weights[r * S + s] = w[e];
+            }
         }
     }
     sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sw = wave_sum(sw);
@@ -308,7 +325,7 @@ int launch_fwd(const float* colors, const float* dens, const float* deltas, cons
                int white, float* rgb, float* weights, float* depth, float* acc, hipStream_t st) {
     const unsigned grid = (unsigned)ceil_div64(R, kWavesPerBlock);
     const bool vec = (EPL % 4 == 0) && (S == 64 * EPL) &&
-                     ((((uintptr_t)colors | (uintptr_t)dens | (uintptr_t)deltas) & 15) == 0);
+                     ((((uintptr_t)colors | (uintptr_t)dens | (uintptr_t)deltas | (uintptr_t)weights | (uintptr_t)t) & 15) == 0);
     if (vec) {
         if constexpr (EPL % 4 == 0)
             composite_fwd_kernel<EPL, true><<<grid, 64 * kWavesPerBlock, 0, st>>>(colors, dens, deltas, t, R, S, per_ray,
