@@ -103,12 +103,14 @@ def side_stream(device) -> "torch.cuda.Stream":
 
 
 def _join_after_backward(device) -> None:
-    """Called inside a backward that ran on the side stream and wrote into a gradient sink (which autograd does
-    not track): make the stream that called backward() wait for it, once the whole backward pass is queued."""
-    if torch.cuda.current_stream(device) is not None and torch.cuda.current_stream(device) == _side_streams.get(
-            torch.device(device).index):
+    """Called inside a backward that wrote into a gradient sink (which autograd does not track).  If it ran on the
+    side stream, make the stream that called backward() wait for it once the whole backward pass is queued: callbacks
+    queued on the autograd engine run at the end of the pass with the caller's streams current."""
+    idx = torch.device(device).index
+    side = _side_streams.get(idx if idx is not None else torch.cuda.current_device())
+    if side is not None and torch.cuda.current_stream(device) == side:
         done = torch.cuda.Event()
-        done.record()
+        done.record(side)
         torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(device).wait_event(done))
 
 
