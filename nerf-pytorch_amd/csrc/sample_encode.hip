@@ -99,6 +99,37 @@ __global__ __launch_bounds__(256) void sample_positions_kernel(const float* __re
     }
 }
 
+// S % 4 == 0: one thread per 4 consecutive samples of a ray -- one 16-byte load of their depths, the ray's origin and
+// direction once, 12 outputs as three 16-byte stores (a wave writes 3 KiB contiguous); one integer division per thread
+__global__ __launch_bounds__(256) void sample_positions_quads_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                                                    const float* __restrict__ t, int64_t R, int S,
+                                                                    int normalize, float nearf, float spanf,
+                                                                    float* __restrict__ pos) {
+    const unsigned Q = (unsigned)S >> 2;                  // quads per ray
+    const int64_t qb = (int64_t)blockIdx.x * 256;         // first quad of this workgroup (uniform)
+    const int64_t rb = qb / Q;
+    const unsigned x = (unsigned)(qb - rb * Q) + threadIdx.x;
+    const unsigned rl = x / Q, sq = x - rl * Q;
+    const int64_t r = rb + rl;
+    if (r >= R) return;
+    const f32x4 tv = *reinterpret_cast<const f32x4*>(t + 4 * sq);
+    float oo[3], dd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { oo[c] = o[r * 3 + c]; dd[c] = d[r * 3 + c]; }
+    float v[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float p = add_rn(oo[c], mul_rn(tv[k], dd[c]));
+            if (normalize) p = normalize_coord(p, nearf, spanf);
+            v[3 * k + c] = p;
+        }
+    f32x4* dst = reinterpret_cast<f32x4*>(pos + (r * S + 4 * sq) * 3);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dst[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+
 extern "C" int nerf_sample_positions(const float* rays_o, const float* rays_d, const float* t, int64_t R, int S,
                                      int normalize, double near, double far, float* pos, void* stream) {
     NERF_REQUIRE(R >= 0 && S >= 1, "nerf_sample_positions: bad R=%lld S=%d", (long long)R, S);
@@ -109,6 +140,11 @@ extern "C" int nerf_sample_positions(const float* rays_o, const float* rays_d, c
     NERF_REQUIRE_PTR(pos);
     const int64_t quads = ceil_div64(R * S * 3, 4);
     NERF_REQUIRE(ceil_div64(quads, 256) < (1ll << 31), "nerf_sample_positions: too many samples");
+    if (S % 4 == 0 && (((uintptr_t)t | (uintptr_t)pos) & 15) == 0) {
+        sample_positions_quads_kernel<<<(unsigned)ceil_div64(R * (S / 4), 256), 256, 0, (hipStream_t)stream>>>(
+            rays_o, rays_d, t, R, S, normalize, (float)near, (float)(far - near), pos);
+        return nerf_check_launch("nerf_sample_positions");
+    }
     sample_positions_kernel<<<(unsigned)ceil_div64(quads, 256), 256, 0, (hipStream_t)stream>>>(
         rays_o, rays_d, t, R, S, normalize, (float)near, (float)(far - near), pos);
     return nerf_check_launch("nerf_sample_positions");
@@ -122,24 +158,33 @@ extern "C" int nerf_sample_positions(const float* rays_o, const float* rays_d, c
 // ---------------------------------------------------------------------------------------
 constexpr int PE_POINTS = 64;
 
-__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x, int64_t M, int D, int L,
-                                                    float* __restrict__ out) {
+template <int D>
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ x, int64_t M, int L, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float rows[];  // [PE_POINTS][width]
     const int per = D * (L + 1), width = D * (1 + 2 * L);
     const int64_t m0 = (int64_t)blockIdx.x * PE_POINTS;
     const int npts = (int)(M - m0 < PE_POINTS ? M - m0 : PE_POINTS);
-    for (int i = threadIdx.x; i < npts * per; i += 256) {
-        const int ml = i / per, rem = i - ml * per;
-        const int j = rem / D, c = rem - j * D;
-        const float v = x[(m0 + ml) * D + c];
+    // lane = point (LDS row stride `width` is odd: conflict-free), the workgroup's four waves share the point's
+    // per = D * (L+1) (slot, coordinate) pairs: wave-uniform slot, no per-thread division
+    const int ml = threadIdx.x & 63;
+    if (ml < npts) {
+        float xv[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) xv[c] = x[(m0 + ml) * D + c];
         float* row = rows + ml * width;
-        if (j == 0) {
-            row[c] = v;
-        } else {
-            float sn, cs;
-            nerf_sincosf(mul_rn((float)(1u << (j - 1)), v), &sn, &cs);
-            row[D + 2 * D * (j - 1) + c] = sn;
-            row[D + 2 * D * (j - 1) + D + c] = cs;
+        for (int jc = threadIdx.x >> 6; jc < per; jc += 4) {
+            const int j = jc / D, c = jc - j * D;
+            float v = xv[0];
+#pragma unroll
+            for (int k = 1; k < D; ++k) v = (c == k) ? xv[k] : v;
+            if (j == 0) {
+                row[c] = v;
+            } else {
+                float sn, cs;
+                nerf_sincosf(mul_rn((float)(1u << (j - 1)), v), &sn, &cs);
+                row[D + 2 * D * (j - 1) + c] = sn;
+                row[D + 2 * D * (j - 1) + D + c] = cs;
+            }
         }
     }
     __syncthreads();
@@ -159,7 +204,13 @@ extern "C" int nerf_posenc_fwd(const float* x, int64_t M, int D, int L, float* o
     const int64_t blocks = ceil_div64(M, PE_POINTS);
     NERF_REQUIRE(blocks < (1ll << 31), "nerf_posenc_fwd: too many elements");
     const int lds = PE_POINTS * D * (1 + 2 * L) * 4;   // at most 64 * 132 * 4 = 33,792 bytes
-    posenc_kernel<<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(x, M, D, L, out);
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 1: posenc_kernel<1><<<(unsigned)blocks, 256, lds, st>>>(x, M, L, out); break;
+        case 2: posenc_kernel<2><<<(unsigned)blocks, 256, lds, st>>>(x, M, L, out); break;
+        case 3: posenc_kernel<3><<<(unsigned)blocks, 256, lds, st>>>(x, M, L, out); break;
+        default: posenc_kernel<4><<<(unsigned)blocks, 256, lds, st>>>(x, M, L, out); break;
+    }
     return nerf_check_launch("nerf_posenc_fwd");
 }
 
@@ -207,18 +258,23 @@ extern "C" int nerf_posenc_bwd(const float* x, const float* grad_out, int64_t M,
 //   comparison result, hence bit-exact for an identical CDF and identical draws.
 // One ray per wavefront.
 // ---------------------------------------------------------------------------------------
-// CDF of one ray by one wave: wr [B] weights -> cr [B+1] (global or LDS)
+// CDF of one ray by one wave: wr [B] weights -> cr [B+1] (global or LDS; each lane re-reads only what it wrote)
 __device__ __forceinline__ void cdf_row(const float* __restrict__ wr, int B, float* cr, int lane) {
     float part = 0.f;
     for (int i = lane; i < B; i += 64) part += wr[i] + 1e-5f;
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
     const float tot = part;
-    // each lane owns a contiguous run of ceil(B/64) bins; wave-exclusive scan of run sums
+    // each lane owns a contiguous run of ceil(B/64) bins: normalised weights parked in cr, wave-exclusive scan of
+    // the run sums, then the running sum replaces them
     const int per = (B + 63) / 64;
     const int b0 = lane * per;
     float run = 0.f;
     for (int i = 0; i < per; ++i)
-        if (b0 + i < B) run += (wr[b0 + i] + 1e-5f) / tot;
+        if (b0 + i < B) {
+            const float q = (wr[b0 + i] + 1e-5f) / tot;
+            cr[b0 + i + 1] = q;
+            run += q;
+        }
     float inc = run;
     for (int off = 1; off < 64; off <<= 1) {
         const float o = __shfl_up(inc, off);
@@ -228,7 +284,7 @@ __device__ __forceinline__ void cdf_row(const float* __restrict__ wr, int B, flo
     if (lane == 0) cr[0] = 0.f;
     for (int i = 0; i < per; ++i)
         if (b0 + i < B) {
-            acc += (wr[b0 + i] + 1e-5f) / tot;
+            acc += cr[b0 + i + 1];
             cr[b0 + i + 1] = acc;
         }
 }
@@ -250,20 +306,44 @@ extern "C" int nerf_weights_to_cdf(const float* weights, int64_t R, int B, float
     return nerf_check_launch("nerf_weights_to_cdf");
 }
 
-// one inverse-CDF draw: c, bn [B+1] (global or LDS) -> sample; *idx = searchsorted(c, uu, right=True)
-__device__ __forceinline__ float pdf_sample(const float* c, const float* bn, int B, float uu, int* idx) {
-    int lo = 0, hi = B + 1;  // first index with cdf[idx] > uu
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (c[mid] <= uu) lo = mid + 1; else hi = mid;
+// #{a[i] <= v} (LE) or #{a[i] < v} (!LE) of the E values v against the ascending a [n], n >= 1 and uniform over
+// the wave: a halving search whose trip count depends on n only, so that the E searches of a lane advance
+// together and every lane runs the same instructions.  The count lies in [base, base + len] throughout.
+template <int E, bool LE>
+__device__ __forceinline__ void count_below(const float* a, int n, const float (&v)[E], int (&cnt)[E]) {
+    int base[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) base[e] = 0;
+    for (int len = n; len > 1;) {
+        const int half = len >> 1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float x = a[base[e] + half - 1];
+            base[e] += (LE ? (x <= v[e]) : (x < v[e])) ? half : 0;
+        }
+        len -= half;
     }
-    const int below = max(lo - 1, 0), above = min(lo, B);
-    const float c0 = c[below], c1 = c[above];
-    float den = sub_rn(c1, c0);
-    if (den < 1e-5f) den = 1.f;
-    const float tt = div_rn(sub_rn(uu, c0), den);
-    *idx = lo;
-    return add_rn(bn[below], mul_rn(tt, sub_rn(bn[above], bn[below])));
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const float x = a[base[e]];
+        cnt[e] = base[e] + ((LE ? (x <= v[e]) : (x < v[e])) ? 1 : 0);
+    }
+}
+
+// inverse-CDF draws: c, bn [B+1] (global or LDS) -> samples; idx = searchsorted(c, uu, right=True)
+template <int E>
+__device__ __forceinline__ void pdf_sample(const float* c, const float* bn, int B, const float (&uu)[E], float (&out)[E],
+                                           int (&idx)[E]) {
+    count_below<E, true>(c, B + 1, uu, idx);     // first index with cdf[idx] > uu
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int below = max(idx[e] - 1, 0), above = min(idx[e], B);
+        const float c0 = c[below], c1 = c[above];
+        float den = sub_rn(c1, c0);
+        if (den < 1e-5f) den = 1.f;
+        const float tt = div_rn(sub_rn(uu[e], c0), den);
+        out[e] = add_rn(bn[below], mul_rn(tt, sub_rn(bn[above], bn[below])));
+    }
 }
 
 __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ bins, const float* __restrict__ cdf,
@@ -272,9 +352,44 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= R * N) return;
     const int64_t r = e / N;
-    int lo;
-    samples[e] = pdf_sample(cdf + r * (B + 1), bins + r * (B + 1), B, u[e], &lo);
-    idx_out[e] = lo;
+    const float uu[1] = {u[e]};
+    float v[1];
+    int lo[1];
+    pdf_sample<1>(cdf + r * (B + 1), bins + r * (B + 1), B, uu, v, lo);
+    samples[e] = v[0];
+    idx_out[e] = lo[0];
+}
+
+// one ray per wave: the ray's CDF and bin edges staged in LDS (2 * (B+1) floats per wave), the draws two per lane at
+// a time so that two searches are in flight
+constexpr int PDF_LDS_MAX_EDGES = 2048;
+__global__ __launch_bounds__(256) void sample_pdf_rows_kernel(const float* __restrict__ bins, const float* __restrict__ cdf,
+                                                             const float* __restrict__ u, int64_t R, int B, int N,
+                                                             float* __restrict__ samples, int32_t* __restrict__ idx_out) {
+    extern __shared__ float pdf_lds[];     // per wave: cdf [B+1] | bins [B+1]
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    if (r >= R) return;                    // waves are independent: no block-wide barrier below
+    float* c = pdf_lds + (size_t)wv * 2 * (B + 1);
+    float* bn = c + (B + 1);
+    for (int i = lane; i <= B; i += 64) {
+        c[i] = cdf[r * (B + 1) + i];
+        bn[i] = bins[r * (B + 1) + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < N; i0 += 128) {
+        const int i[2] = {i0 + lane, i0 + 64 + lane};
+        const float uu[2] = {i[0] < N ? u[r * N + i[0]] : 0.f, i[1] < N ? u[r * N + i[1]] : 0.f};
+        float v[2];
+        int lo[2];
+        pdf_sample<2>(c, bn, B, uu, v, lo);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (i[e] < N) {
+                samples[r * N + i[e]] = v[e];
+                idx_out[r * N + i[e]] = lo[e];
+            }
+    }
 }
 
 extern "C" int nerf_sample_pdf(const float* bins, const float* cdf, const float* u, int64_t R, int B, int N,
@@ -286,6 +401,13 @@ extern "C" int nerf_sample_pdf(const float* bins, const float* cdf, const float*
     NERF_REQUIRE_PTR(u);
     NERF_REQUIRE_PTR(samples);
     NERF_REQUIRE_PTR(idx);
+    if (B + 1 <= PDF_LDS_MAX_EDGES) {
+        NERF_REQUIRE(ceil_div64(R, 4) < (1ll << 31), "nerf_sample_pdf: too many rays");
+        const size_t lds = 4 * 2 * (size_t)(B + 1) * sizeof(float);     // at most 64 KiB
+        if (int rc = nerf_set_lds(sample_pdf_rows_kernel, (int)lds)) return rc;
+        sample_pdf_rows_kernel<<<(unsigned)ceil_div64(R, 4), 256, lds, (hipStream_t)stream>>>(bins, cdf, u, R, B, N, samples, idx);
+        return nerf_check_launch("nerf_sample_pdf");
+    }
     NERF_REQUIRE(ceil_div64(R * N, 256) < (1ll << 31), "nerf_sample_pdf: too many samples");
     sample_pdf_kernel<<<(unsigned)ceil_div64(R * N, 256), 256, 0, (hipStream_t)stream>>>(bins, cdf, u, R, B, N, samples,
                                                                                       idx);
@@ -338,79 +460,150 @@ extern "C" int nerf_compute_rays(const float* c2w, int64_t N, int H, int W, doub
 // sorted union of the shared coarse depths and each ray's fine depths (canonical NeRF:
 // sort(cat(z_vals, z_samples))) plus the successive differences the compositor needs.
 // One ray per wavefront.  The coarse depths are already ascending, so only the ray's fine depths are
-// sorted (bitonic, padded with +inf, in LDS); every element then finds its place in the union by a
-// binary search in the OTHER list: fine[i] goes to i + #{coarse <= fine[i]}, coarse[j] to
-// j + #{fine < coarse[j]}.  A wave only touches its own LDS rows and LDS operations of one wave are
-// carried out in program order, so the stages are separated by wave-level scheduling barriers only.
+// sorted: a bitonic network over 64*E values held E per lane in registers (padded with +inf), whose
+// exchanges are register moves inside a lane and cross-lane shuffles between lanes -- no LDS traffic and
+// every lane busy in every stage.  Every element then finds its place in the union by a binary search in
+// the OTHER list: fine[i] goes to i + #{coarse <= fine[i]}, coarse[j] to j + #{fine < coarse[j]}.  A wave
+// only touches its own LDS rows and LDS operations of one wave are carried out in program order, so the
+// stages are separated by wave-level scheduling barriers only.
 // ---------------------------------------------------------------------------------------
 #define MERGE_MAX 1024
-// sorts b [N] (the ray's fine depths padded with +inf) and merges it with the ascending c [Sc] into o [Sc+Sf]
-__device__ __forceinline__ void merge_row(float* b, const float* c, float* o, int Sc, int Sf, int N, int lane) {
-    for (int k = 2; k <= N; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < N; i += 64) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const float x = b[i], y = b[p];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) { b[i] = y; b[p] = x; }
-                }
+
+// value of lane ^ M: data-parallel-primitive moves where one exists (quad permutes, rotation by 8 in a row of 16),
+// a cross-lane LDS permute otherwise
+template <int M>
+__device__ __forceinline__ float lane_xor(float v) {
+    const int x = __float_as_int(v);
+    if constexpr (M == 1) return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
+    else if constexpr (M == 8) return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true)); // row_ror:8
+    else return __shfl_xor(v, M);
+}
+
+// one compare-exchange stage of the bitonic network (K: length of the bitonic runs being merged, J: partner distance)
+template <int E, int K, int J>
+__device__ __forceinline__ void sort_stage(float (&f)[E], int lane) {
+    constexpr int N = 64 * E;
+    // median of (a, b, -inf) is min(a, b), of (a, b, +inf) max(a, b): one instruction per value once the lane knows
+    // which of the two it keeps in this stage
+    if constexpr (J >= E) {             // partner in lane ^ (J/E), same register
+        constexpr int M = J / E;
+        // the lower index keeps the smaller value in an ascending run ((index & K) == 0), the larger in a descending one
+        const bool keep_min = ((lane & M) == 0) == (K >= N || (lane & (K / E)) == 0);
+        const float sel = keep_min ? -INFINITY : INFINITY;
+#pragma unroll
+        for (int e = 0; e < E; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e], lane_xor<M>(f[e]), sel);
+    } else if constexpr (K < E) {       // partner in the same lane, direction known at compile time
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if ((e & J) == 0) {
+                const float x = f[e], y = f[e | J];
+                const bool up = (e & K) == 0;
+                f[e] = up ? fminf(x, y) : fmaxf(x, y);
+                f[e | J] = up ? fmaxf(x, y) : fminf(x, y);
             }
-            __builtin_amdgcn_wave_barrier();
-        }
-    for (int i = lane; i < Sf; i += 64) {       // #{coarse <= v}: first index with coarse > v
-        const float v = b[i];
-        int lo = 0, hi = Sc;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (c[mid] <= v) lo = mid + 1; else hi = mid;
-        }
-        o[i + lo] = v;
+    } else {                            // partner in the same lane, direction by lane
+        const bool up = K >= N || (lane & (K / E)) == 0;
+        const float sel_lo = up ? -INFINITY : INFINITY, sel_hi = up ? INFINITY : -INFINITY;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if ((e & J) == 0) {
+                const float x = f[e], y = f[e | J];
+                f[e] = __builtin_amdgcn_fmed3f(x, y, sel_lo);
+                f[e | J] = __builtin_amdgcn_fmed3f(x, y, sel_hi);
+            }
     }
-    for (int j = lane; j < Sc; j += 64) {       // #{fine < v}: first index with fine >= v
-        const float v = c[j];
-        int lo = 0, hi = Sf;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (b[mid] < v) lo = mid + 1; else hi = mid;
-        }
-        o[j + lo] = v;
+}
+
+template <int E, int K, int J>
+__device__ __forceinline__ void sort_merge(float (&f)[E], int lane) {
+    sort_stage<E, K, J>(f, lane);
+    if constexpr (J > 1) sort_merge<E, K, J / 2>(f, lane);
+}
+
+template <int E, int K>
+__device__ __forceinline__ void sort_runs(float (&f)[E], int lane) {
+    sort_merge<E, K, K / 2>(f, lane);
+    if constexpr (K < 64 * E) sort_runs<E, K * 2>(f, lane);
+}
+
+// ascending sort of the wave's 64*E values (no NaNs); value (lane, e) has index lane*E + e before and after
+template <int E>
+__device__ __forceinline__ void wave_sort(float (&f)[E], int lane) {
+    sort_runs<E, 2>(f, lane);
+}
+
+// f: the ray's fine depths (Sf of them, the rest +inf), unsorted, E per lane; c [Sc] ascending coarse depths (LDS);
+// b [64*E] LDS scratch; writes the sorted union to o [Sc+Sf] (LDS)
+template <int E>
+__device__ __forceinline__ void merge_row(float (&f)[E], float* b, const float* c, float* o, int Sc, int Sf, int lane) {
+    wave_sort<E>(f, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) b[lane * E + e] = f[e];
+    int cnt[E];
+    count_below<E, true>(c, Sc, f, cnt);        // #{coarse <= fine value}
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane * E + e;
+        if (i < Sf) o[i + cnt[e]] = f[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < Sc; j += 64) {       // #{fine < coarse value}; b holds 64*E >= 1 sorted values, the padding last
+        const float v[1] = {c[j]};
+        int lo[1];
+        count_below<1, false>(b, Sf > 0 ? Sf : 1, v, lo);
+        o[j + (Sf > 0 ? lo[0] : 0)] = v[0];
     }
     __builtin_amdgcn_wave_barrier();
 }
 
+// the union and its successive differences, LDS -> global (row r)
+__device__ __forceinline__ void store_union(const float* o, int S, int64_t r, float* __restrict__ t_all,
+                                            float* __restrict__ deltas, int lane) {
+    for (int i = lane; i < S; i += 64) {
+        const float v = o[i];
+        t_all[r * S + i] = v;
+        deltas[r * S + i] = (i + 1 < S) ? sub_rn(o[i + 1], v) : 1e10f;
+    }
+}
+
+template <int E>
 __global__ __launch_bounds__(256) void merge_samples_kernel(const float* __restrict__ tc, const float* __restrict__ tf,
-                                                           int64_t R, int Sc, int Sf, int N, float* __restrict__ t_all,
+                                                           int64_t R, int Sc, int Sf, float* __restrict__ t_all,
                                                            float* __restrict__ deltas) {
-    extern __shared__ float merge_lds[];   // per wave: fine [N] | coarse [Sc] | union [Sc+Sf]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    extern __shared__ float merge_lds[];   // per wave: fine [64*E] | coarse [Sc] | union [Sc+Sf]
+    constexpr int N = 64 * E;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar row addresses
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     const int64_t rr = r < R ? r : R - 1;  // out-of-range waves redo the last ray and store nothing
     const int S = Sc + Sf;
     float* b = merge_lds + (size_t)wv * (N + Sc + S);
     float* c = b + N;
     float* o = c + Sc;
-    for (int i = lane; i < N; i += 64) b[i] = i < Sf ? tf[rr * Sf + i] : INFINITY;
+    float f[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane * E + e;
+        f[e] = i < Sf ? tf[rr * Sf + i] : INFINITY;
+    }
     for (int i = lane; i < Sc; i += 64) c[i] = tc[i];
     __builtin_amdgcn_wave_barrier();
-    merge_row(b, c, o, Sc, Sf, N, lane);
-    if (r < R)
-        for (int i = lane; i < S; i += 64) {
-            t_all[r * S + i] = o[i];
-            deltas[r * S + i] = (i + 1 < S) ? sub_rn(o[i + 1], o[i]) : 1e10f;
-        }
+    merge_row<E>(f, b, c, o, Sc, Sf, lane);
+    if (r < R) store_union(o, S, r, t_all, deltas, lane);
 }
 
 // Fused re-sampling of one ray per wave: CDF of the interior coarse weights over the mid-points of the coarse
 // depths, Nf inverse-CDF draws, sorted union with the coarse depths, successive differences -- the chain
 // weights_to_cdf -> sample_pdf -> merge_samples in ONE launch, built from the same device functions (bitwise
-// the same results), with CDF, mid-points and fine depths kept in LDS instead of going through HBM.
+// the same results), with CDF, mid-points and fine depths kept in LDS / registers instead of going through HBM.
+template <int E>
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ w, const float* __restrict__ tc,
-                                                      const float* __restrict__ u, int64_t R, int Sc, int Sf, int N,
+                                                      const float* __restrict__ u, int64_t R, int Sc, int Sf,
                                                       float* __restrict__ t_all, float* __restrict__ deltas,
                                                       float* __restrict__ t_fine, int32_t* __restrict__ idx_out) {
-    extern __shared__ float merge_lds[];   // per wave: fine [N] | coarse [Sc] | union [Sc+Sf] | cdf [Sc-1] | mid [Sc-1]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    extern __shared__ float merge_lds[];   // per wave: fine [64*E] | coarse [Sc] | union [Sc+Sf] | cdf [Sc-1] | mid [Sc-1]
+    constexpr int N = 64 * E;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar row addresses
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     const int64_t rr = r < R ? r : R - 1;  // out-of-range waves redo the last ray and store nothing
     const int S = Sc + Sf, B = Sc - 2;
@@ -419,30 +612,38 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     float* o = c + Sc;
     float* cdf = o + S;
     float* mid = cdf + (Sc - 1);
+    float uu[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {               // issued first: the draws are the bulk of the ray's input
+        const int i = lane * E + e;
+        uu[e] = i < Sf ? u[rr * Sf + i] : 0.f;
+    }
     for (int i = lane; i < Sc; i += 64) c[i] = tc[i];
     cdf_row(w + rr * Sc + 1, B, cdf, lane);                      // interior weights w[1 .. Sc-2]
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < Sc - 1; i += 64) mid[i] = mul_rn(0.5f, add_rn(c[i + 1], c[i]));
     __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < N; i += 64) {
-        float v = INFINITY;
-        if (i < Sf) {
-            int lo;
-            v = pdf_sample(cdf, mid, B, u[rr * Sf + i], &lo);
-            if (r < R) {
-                if (t_fine) t_fine[r * Sf + i] = v;
-                if (idx_out) idx_out[r * Sf + i] = lo;
-            }
+    float f[E];
+    int lo[E];
+    pdf_sample<E>(cdf, mid, B, uu, f, lo);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane * E + e;
+        if (r < R && i < Sf) {
+            if (t_fine) t_fine[r * Sf + i] = f[e];
+            if (idx_out) idx_out[r * Sf + i] = lo[e];
         }
-        b[i] = v;
+        if (i >= Sf) f[e] = INFINITY;
     }
-    __builtin_amdgcn_wave_barrier();
-    merge_row(b, c, o, Sc, Sf, N, lane);
-    if (r < R)
-        for (int i = lane; i < S; i += 64) {
-            t_all[r * S + i] = o[i];
-            deltas[r * S + i] = (i + 1 < S) ? sub_rn(o[i + 1], o[i]) : 1e10f;
-        }
+    merge_row<E>(f, b, c, o, Sc, Sf, lane);
+    if (r < R) store_union(o, S, r, t_all, deltas, lane);
+}
+
+// values per lane of the sorting network for Sf fine depths: the power of two >= Sf / 64
+static int sort_width(int Sf) {
+    int E = 1;
+    while (64 * E < Sf) E <<= 1;
+    return E;
 }
 
 extern "C" int nerf_merge_samples(const float* t_coarse, const float* t_fine, int64_t R, int Sc, int Sf, float* t_all,
@@ -454,11 +655,13 @@ extern "C" int nerf_merge_samples(const float* t_coarse, const float* t_fine, in
     if (Sf > 0) NERF_REQUIRE_PTR(t_fine);
     NERF_REQUIRE_PTR(t_all);
     NERF_REQUIRE_PTR(deltas);
-    int N = 2;   // bitonic length: the fine depths padded to a power of two
-    while (N < Sf) N <<= 1;
+    const int E = sort_width(Sf), N = 64 * E;
     const size_t lds = 4 * (size_t)(N + 2 * Sc + Sf) * sizeof(float);   // at most 4 * 3072 * 4 = 48 KiB
-    merge_samples_kernel<<<(unsigned)ceil_div64(R, 4), 256, lds, (hipStream_t)stream>>>(t_coarse, t_fine, R, Sc, Sf, N,
-                                                                                       t_all, deltas);
+    const unsigned grid = (unsigned)ceil_div64(R, 4);
+    hipStream_t st = (hipStream_t)stream;
+#define NERF_MERGE_CASE(EE) case EE: merge_samples_kernel<EE><<<grid, 256, lds, st>>>(t_coarse, t_fine, R, Sc, Sf, t_all, deltas); break
+    switch (E) { NERF_MERGE_CASE(1); NERF_MERGE_CASE(2); NERF_MERGE_CASE(4); NERF_MERGE_CASE(8); default: NERF_MERGE_CASE(16); }
+#undef NERF_MERGE_CASE
     return nerf_check_launch("nerf_merge_samples");
 }
 
@@ -472,11 +675,16 @@ extern "C" int nerf_resample(const float* weights, const float* t_coarse, const 
     NERF_REQUIRE_PTR(u);
     NERF_REQUIRE_PTR(t_all);
     NERF_REQUIRE_PTR(deltas);
-    int N = 2;   // bitonic length: the fine depths padded to a power of two
-    while (N < Sf) N <<= 1;
+    const int E = sort_width(Sf), N = 64 * E;
     const size_t lds = 4 * (size_t)(N + 2 * Sc + Sf + 2 * (Sc - 1)) * sizeof(float);   // at most 4 * 5118 * 4 = 80 KiB
-    if (int rc = nerf_set_lds(resample_kernel, (int)lds)) return rc;
-    resample_kernel<<<(unsigned)ceil_div64(R, 4), 256, lds, (hipStream_t)stream>>>(weights, t_coarse, u, R, Sc, Sf, N, t_all,
-                                                                                  deltas, t_fine, idx);
+    const unsigned grid = (unsigned)ceil_div64(R, 4);
+    hipStream_t st = (hipStream_t)stream;
+#define NERF_RESAMPLE_CASE(EE)                                                                              \
+    case EE:                                                                                                \
+        if (int rc = nerf_set_lds(resample_kernel<EE>, (int)lds)) return rc;                                \
+        resample_kernel<EE><<<grid, 256, lds, st>>>(weights, t_coarse, u, R, Sc, Sf, t_all, deltas, t_fine, idx); \
+        break
+    switch (E) { NERF_RESAMPLE_CASE(1); NERF_RESAMPLE_CASE(2); NERF_RESAMPLE_CASE(4); NERF_RESAMPLE_CASE(8); default: NERF_RESAMPLE_CASE(16); }
+#undef NERF_RESAMPLE_CASE
     return nerf_check_launch("nerf_resample");
 }
