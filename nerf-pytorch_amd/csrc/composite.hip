@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_bwd_kernel(
     const float* __restrict__ colors, const float* __restrict__ dens, const float* __restrict__ deltas, int64_t R,
     int S, int per_ray, int white, const float* __restrict__ grad_rgb, float* __restrict__ dcolors,
     float* __restrict__ ddens) {
+    __shared__ __attribute__((aligned(16))) float stage[VEC ? kWavesPerBlock * 64 * EPL * 3 : 4];   // VEC: one row of color gradients per wave
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -215,7 +216,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_bwd_kernel(
     const int s0 = lane * EPL;
     if constexpr (VEC) {
         f32x4* dp = reinterpret_cast<f32x4*>(ddens + r * S + s0);
-        f32x4* cp = reinterpret_cast<f32x4*>(dcolors + (r * S + s0) * 3);
 #pragma unroll
         for (int q = 0; q < EPL / 4; ++q) {
             f32x4 v;
@@ -223,17 +223,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_bwd_kernel(
             for (int k = 0; k < 4; ++k) v[k] = dsig[4 * q + k];
             dp[q] = v;
         }
+        // the lane's 3*EPL color gradients are contiguous in the ray's row but 12*EPL bytes from the next lane's:
+        // they pass through the wave's LDS row so that every store instruction writes 1 KiB contiguous
+        // (16-byte pieces 48+ bytes apart reach about half the store rate)
+        float* row = stage + (threadIdx.x >> 6) * (64 * EPL * 3);
+        f32x4* mine = reinterpret_cast<f32x4*>(row + lane * (EPL * 3));
         float flat[EPL * 3];
 #pragma unroll
         for (int e = 0; e < EPL; ++e)
 #pragma unroll
             for (int c = 0; c < 3; ++c) flat[3 * e + c] = dcol[e][c];
 #pragma unroll
-        for (int q = 0; q < EPL * 3 / 4; ++q) {
-            f32x4 v;
+        for (int q = 0; q < EPL * 3 / 4; ++q) mine[q] = f32x4{flat[4 * q], flat[4 * q + 1], flat[4 * q + 2], flat[4 * q + 3]};
+        __builtin_amdgcn_wave_barrier();          // a wave's LDS operations complete in program order
+        float* crow = dcolors + r * S * 3;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = flat[4 * q + k];
-            cp[q] = v;
+        for (int q = 0; q < EPL * 3 / 4; ++q) {
+            const int fl = (q * 64 + lane) * 4;
+            *reinterpret_cast<f32x4*>(crow + fl) = *reinterpret_cast<const f32x4*>(row + fl);
         }
     } else {
 #pragma unroll

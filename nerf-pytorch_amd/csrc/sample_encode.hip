@@ -100,34 +100,45 @@ __global__ __launch_bounds__(256) void sample_positions_kernel(const float* __re
 }
 
 // S % 4 == 0: one thread per 4 consecutive samples of a ray -- one 16-byte load of their depths, the ray's origin and
-// direction once, 12 outputs as three 16-byte stores (a wave writes 3 KiB contiguous); one integer division per thread
+// direction once, one integer division per thread.  The workgroup's 256 quads are contiguous in the output
+// (3072 floats); they pass through LDS so that every store instruction of a wave writes 1 KiB contiguous
+// (12 floats per lane written directly would put 16-byte pieces 48 bytes apart: about half the store rate).
 __global__ __launch_bounds__(256) void sample_positions_quads_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                                                     const float* __restrict__ t, int64_t R, int S,
                                                                     int normalize, float nearf, float spanf,
                                                                     float* __restrict__ pos) {
+    __shared__ __attribute__((aligned(16))) float stage[256 * 12];
     const unsigned Q = (unsigned)S >> 2;                  // quads per ray
     const int64_t qb = (int64_t)blockIdx.x * 256;         // first quad of this workgroup (uniform)
     const int64_t rb = qb / Q;
     const unsigned x = (unsigned)(qb - rb * Q) + threadIdx.x;
     const unsigned rl = x / Q, sq = x - rl * Q;
     const int64_t r = rb + rl;
-    if (r >= R) return;
-    const f32x4 tv = *reinterpret_cast<const f32x4*>(t + 4 * sq);
-    float oo[3], dd[3];
+    if (r < R) {
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(t + 4 * sq);
+        float oo[3], dd[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { oo[c] = o[r * 3 + c]; dd[c] = d[r * 3 + c]; }
-    float v[12];
+        for (int c = 0; c < 3; ++c) { oo[c] = o[r * 3 + c]; dd[c] = d[r * 3 + c]; }
+        float v[12];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float p = add_rn(oo[c], mul_rn(tv[k], dd[c]));
-            if (normalize) p = normalize_coord(p, nearf, spanf);
-            v[3 * k + c] = p;
-        }
-    f32x4* dst = reinterpret_cast<f32x4*>(pos + (r * S + 4 * sq) * 3);
+            for (int c = 0; c < 3; ++c) {
+                float p = add_rn(oo[c], mul_rn(tv[k], dd[c]));
+                if (normalize) p = normalize_coord(p, nearf, spanf);
+                v[3 * k + c] = p;
+            }
+        f32x4* mine = reinterpret_cast<f32x4*>(stage + threadIdx.x * 12);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) dst[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        for (int q = 0; q < 3; ++q) mine[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    }
+    __syncthreads();
+    const int64_t f0 = qb * 12, total = R * S * 3;        // both multiples of 4
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int fl = (q * 256 + threadIdx.x) * 4;
+        if (f0 + fl < total) *reinterpret_cast<f32x4*>(pos + f0 + fl) = *reinterpret_cast<const f32x4*>(stage + fl);
+    }
 }
 
 extern "C" int nerf_sample_positions(const float* rays_o, const float* rays_d, const float* t, int64_t R, int S,
@@ -258,12 +269,44 @@ extern "C" int nerf_posenc_bwd(const float* x, const float* grad_out, int64_t M,
 //   comparison result, hence bit-exact for an identical CDF and identical draws.
 // One ray per wavefront.
 // ---------------------------------------------------------------------------------------
+// data-parallel-primitive moves (no LDS round trip): lanes the pattern leaves without a source read 0
+#define NERF_DPP_ROW_SHR(n) (0x110 + (n))
+#define NERF_DPP_ROW_SHL(n) (0x100 + (n))
+#define NERF_DPP_ROW_ROR(n) (0x120 + (n))
+#define NERF_DPP_ROW_BCAST15 0x142
+#define NERF_DPP_ROW_BCAST31 0x143
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_or_zero(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+
+// sum over the wave, in every lane
+__device__ __forceinline__ float wave_total(float v) {
+    v += dpp_or_zero<NERF_DPP_ROW_SHR(1)>(v);
+    v += dpp_or_zero<NERF_DPP_ROW_SHR(2)>(v);
+    v += dpp_or_zero<NERF_DPP_ROW_SHR(4)>(v);
+    v += dpp_or_zero<NERF_DPP_ROW_SHR(8)>(v);           // lane 15 of each row: the row's sum
+    v += dpp_or_zero<NERF_DPP_ROW_BCAST15, 0xA>(v);     // rows 1 and 3 add the row before
+    v += dpp_or_zero<NERF_DPP_ROW_BCAST31, 0xC>(v);     // rows 2 and 3 add lane 31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// inclusive prefix sum over the lanes of the wave
+__device__ __forceinline__ float wave_inclusive_sum(float v) {
+    v += dpp_or_zero<NERF_DPP_ROW_SHR(1)>(v);
+    v += dpp_or_zero<NERF_DPP_ROW_SHR(2)>(v);
+    v += dpp_or_zero<NERF_DPP_ROW_SHR(4)>(v);
+    v += dpp_or_zero<NERF_DPP_ROW_SHR(8)>(v);
+    v += dpp_or_zero<NERF_DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_or_zero<NERF_DPP_ROW_BCAST31, 0xC>(v);
+    return v;
+}
+
 // CDF of one ray by one wave: wr [B] weights -> cr [B+1] (global or LDS; each lane re-reads only what it wrote)
 __device__ __forceinline__ void cdf_row(const float* __restrict__ wr, int B, float* cr, int lane) {
     float part = 0.f;
     for (int i = lane; i < B; i += 64) part += wr[i] + 1e-5f;
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-    const float tot = part;
+    const float tot = wave_total(part);
     // each lane owns a contiguous run of ceil(B/64) bins: normalised weights parked in cr, wave-exclusive scan of
     // the run sums, then the running sum replaces them
     const int per = (B + 63) / 64;
@@ -275,12 +318,7 @@ __device__ __forceinline__ void cdf_row(const float* __restrict__ wr, int B, flo
             cr[b0 + i + 1] = q;
             run += q;
         }
-    float inc = run;
-    for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-    }
-    float acc = inc - run;
+    float acc = wave_inclusive_sum(run) - run;
     if (lane == 0) cr[0] = 0.f;
     for (int i = 0; i < per; ++i)
         if (b0 + i < B) {
@@ -476,7 +514,10 @@ __device__ __forceinline__ float lane_xor(float v) {
     const int x = __float_as_int(v);
     if constexpr (M == 1) return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
     else if constexpr (M == 2) return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
-    else if constexpr (M == 8) return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true)); // row_ror:8
+    else if constexpr (M == 4) {     // banks 0 and 2 of a row (lanes with bit 2 clear) read 4 lanes up, banks 1 and 3 4 lanes down
+        const int up = __builtin_amdgcn_update_dpp(x, x, NERF_DPP_ROW_SHL(4), 0xF, 0x5, false);
+        return __int_as_float(__builtin_amdgcn_update_dpp(up, x, NERF_DPP_ROW_SHR(4), 0xF, 0xA, false));
+    } else if constexpr (M == 8) return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true)); // row_ror:8
     else return __shfl_xor(v, M);
 }
 
