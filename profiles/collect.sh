@@ -40,7 +40,7 @@ if [ "$ONLY" = modes ]; then
     modes && echo "modes collected in $OUT"
     exit $?
 fi
-stats hier --steps 6 --warmup 2 &&
+stats hier &&    # the default bench command itself (10 timed steps after 3 warm-ups)
 stats single --steps 6 --warmup 2 --sampling single &&
 stats siren --steps 6 --warmup 2 --sampling single --model siren &&
 pmc fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
