@@ -110,6 +110,21 @@ def test_positions_non_dyadic_bounds_bit_exact(hip):
     assert np.array_equal(got.cpu().numpy(), ref.numpy())
 
 
+@pytest.mark.parametrize("S,normalize", [(52, True), (52, False), (50, False), (4, True)])
+def test_positions_ragged_bit_exact(hip, S, normalize):
+    """Both kernels behind nerf_sample_positions (four samples per thread when S % 4 == 0, one output quad per
+    thread otherwise) on ray counts that leave the last workgroup partly empty."""
+    g = torch.Generator().manual_seed(S)
+    for R in (1, 37, 300):
+        o, d = rays(R, 5)
+        t_ref = O.stratified_t(0.7, 5.3, S, torch.rand(S, generator=g))
+        ref = O.sample_positions(o, d, t_ref)
+        if normalize:
+            ref = O.normalize_positions(ref, 0.7, 5.3)
+        got = hip.sample_positions(o.to(DEV), d.to(DEV), t_ref.to(DEV), normalize, 0.7, 5.3)
+        assert np.array_equal(got.cpu().numpy(), ref.numpy())
+
+
 # ----------------------------------------------------------------------------- encoding
 def test_posenc_golden(golden):
     from nerf.encoding import positional_encoding
@@ -125,10 +140,11 @@ def test_posenc_golden(golden):
 def test_posenc_shapes_and_empty():
     from nerf.encoding import positional_encoding
     assert positional_encoding(torch.zeros(0, 3, device=DEV), 10).shape == (0, 63)
-    x = torch.rand(1000, 2, device=DEV) * 4 - 2
-    out = positional_encoding(x, 3)
-    ref = O.positional_encoding(x.cpu(), 3)
-    assert out.shape == ref.shape and (out.cpu() - ref).abs().max() <= 2.5e-7
+    for D, L, M in ((2, 3, 1000), (1, 5, 77), (4, 0, 65), (3, 10, 1)):
+        x = torch.rand(M, D, device=DEV) * 4 - 2
+        out = positional_encoding(x, L)
+        ref = O.positional_encoding(x.cpu(), L)
+        assert out.shape == ref.shape and (out.cpu() - ref).abs().max() <= 2.5e-7
 
 
 # ----------------------------------------------------------------------------- compositing
@@ -154,7 +170,7 @@ def test_composite_golden(hip, golden, wb):
     assert rel(acc, z["weights"].sum(1)) < RTOL
 
 
-@pytest.mark.parametrize("S", [1, 7, 64, 100, 192, 256, 512, 1000])
+@pytest.mark.parametrize("S", [1, 7, 64, 100, 192, 256, 512, 1000, 1024])
 def test_composite_random_sizes(hip, S):
     g = torch.Generator().manual_seed(S)
     R = 301
