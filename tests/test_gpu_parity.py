@@ -707,7 +707,7 @@ def test_sample_pdf_indices_bit_exact(hip):
 
 def test_merge_samples_sorted_union(hip):
     g = torch.Generator().manual_seed(8)
-    for R, Sc, Sf in [(130, 64, 128), (5, 7, 0 + 3), (33, 100, 411), (4, 512, 512)]:
+    for R, Sc, Sf in [(130, 64, 128), (5, 7, 0 + 3), (33, 100, 411), (4, 512, 512), (3, 3, 1021), (2, 1, 64), (6, 90, 200)]:
         t_c = O.stratified_t(2.0, 6.0, Sc, torch.rand(Sc, generator=g))
         t_f = torch.rand(R, Sf, generator=g) * 4 + 2
         t_all, deltas = hip.merge_samples(t_c.to(DEV), t_f.to(DEV))
@@ -907,7 +907,8 @@ def test_model_input_gradients_vs_oracle(tag):
     assert rel(c2, colors) < RTOL and rel(d2, dens) < RTOL
 
 
-@pytest.mark.parametrize("R,Sc,Sf", [(257, 64, 128), (5, 3, 1), (33, 17, 100), (4, 512, 512), (130, 64, 192)])
+@pytest.mark.parametrize("R,Sc,Sf", [(257, 64, 128), (5, 3, 1), (33, 17, 100), (4, 512, 512), (130, 64, 192), (3, 3, 1021), (6, 200, 600),
+                                     (9, 64, 64), (7, 65, 33)])
 def test_fused_resample_equals_the_three_steps(hip, R, Sc, Sf):
     """nerf_resample (one launch between the coarse and the fine pass) against nerf_weights_to_cdf ->
     nerf_sample_pdf -> nerf_merge_samples on the same inputs: bit for bit, indices included."""
