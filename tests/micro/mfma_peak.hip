@@ -5,6 +5,7 @@
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <int WAVES_PER_SIMD>
@@ -298,6 +299,88 @@ int run_layered(const char* name, float* out, const float* w, hipEvent_t e0, hip
     return 0;
 }
 
+// Wave-tile shapes of the K loop with the kernel's per-block ingredients: MT row tiles x NT column tiles of 32x32
+// (MT*NT == 4: 64 accumulator registers), MT LDS A-fragment reads + NT buffer-load B fragments per 16 MFMAs;
+// COPY adds the training forward's workspace copy (one 16-byte LDS read and one non-temporal 16-byte buffer store
+// per thread and K block).
+template <int MT_, int NT_, int COPY>
+__global__ __launch_bounds__(256, 2) void shaped_t(float* out, const float* __restrict__ w, float* __restrict__ ws, int iters) {
+    static_assert(MT_ * NT_ == 4, "64 accumulator registers");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 260; i += 256) lds[i] = (float)(i % 97) * 1e-3f;
+    __syncthreads();
+    f32x16 acc[MT_][NT_];
+    for (int i = 0; i < MT_; ++i) for (int j = 0; j < NT_; ++j) for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+    // waves tile the 64 x 256 output: (2 / MT_) row groups x (4 * MT_ / 2 ... ) column groups
+    constexpr int ROWG = 2 / MT_;                  // row groups of 32*MT_ rows
+    const int rg = wave % ROWG, cg = wave / ROWG;  // column group of 32*NT_ columns
+    const float* ap = lds + (rg * 32 * MT_ + (lane & 31)) * 260 + 4 * (lane >> 5);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, 12 * 65536 * 4, 0x00020000);
+    const int voff = ((cg * 32 * NT_ + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4;
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)blockIdx.x * 64 * 256, 0, 64 * 256 * 4, 0x00020000);
+    f32x4 a0[MT_], b0[NT_], a1[MT_], b1[NT_];
+    for (int i = 0; i < MT_; ++i) for (int k = 0; k < 4; ++k) a0[i][k] = a1[i][k] = 1e-3f * lane;
+    for (int i = 0; i < NT_; ++i) for (int k = 0; k < 4; ++k) b0[i][k] = b1[i][k] = 2e-3f * lane;
+    auto ld = [&](int kb, f32x4 (&a)[MT_], f32x4 (&b)[NT_]) {
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni)
+            b[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + ni * 1024, kb * 8192, 0));
+#pragma unroll
+        for (int mi = 0; mi < MT_; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(ap + mi * 32 * 260 + kb * 8);
+    };
+    auto mm = [&](f32x4 (&a)[MT_], f32x4 (&b)[NT_]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MT_; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT_; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+    };
+    f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+    // COPY 1: store + read with the first burst; 2: with the second burst; 3: store in the first, read in the second
+    auto copy_store = [&](int kb) {  // 512 pieces of 16 bytes per K-block pair: thread t stores the piece it read one block earlier
+        const int piece = (kb >> 1) * 256 + threadIdx.x;          // 4096 pieces = 64 rows x 64 pieces
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cp), wsrc, piece * 16, 0, 2);
+    };
+    auto copy_read = [&](int kb) {
+        const int nxt = ((kb >> 1) + 1) % 16 * 256 + threadIdx.x;
+        cp = *reinterpret_cast<const f32x4*>(lds + (nxt >> 6) * 260 + (nxt & 63) * 4);
+    };
+    for (int it = 0; it < iters; ++it) {
+        ld(0, a0, b0);
+#pragma unroll 1
+        for (int kb = 0; kb < 32; kb += 2) {
+            ld(kb + 1, a1, b1);
+            if constexpr (COPY == 1 || COPY == 3) copy_store(kb);
+            if constexpr (COPY == 1) copy_read(kb);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            ld(kb + 2 < 32 ? kb + 2 : kb, a0, b0);
+            if constexpr (COPY == 2) copy_store(kb);
+            if constexpr (COPY == 2 || COPY == 3) copy_read(kb);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0; for (int i = 0; i < MT_; ++i) for (int j = 0; j < NT_; ++j) for (int k = 0; k < 16; ++k) s += acc[i][j][k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int MT_, int NT_, int COPY>
+int run_shaped_t(const char* name, float* out, const float* w, float* ws, hipEvent_t e0, hipEvent_t e1, int grid) {
+    int iters = 400;
+    CK(hipFuncSetAttribute((const void*)shaped_t<MT_, NT_, COPY>, hipFuncAttributeMaxDynamicSharedMemorySize, 66560));
+    shaped_t<MT_, NT_, COPY><<<grid, 256, 66560>>>(out, w, ws, 20);
+    CK(hipEventRecord(e0)); shaped_t<MT_, NT_, COPY><<<grid, 256, 66560>>>(out, w, ws, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s %8.3f ms  %7.1f TFLOP/s\n", name, ms, (double)grid * 4 * iters * 32 * 16 * 4096.0 / ms / 1e9);
+    return 0;
+}
+
 int main() {
     float *out, *w;
     CK(hipMalloc(&out, 2048 * 256 * 4));
@@ -344,6 +427,19 @@ int main() {
     run_shaped<3>("K loop: A + B burst, 1 WG/CU", out, w, e0, e1, 256);
     run_shaped<7>("K loop: A + B spread, 1 WG/CU", out, w, e0, e1, 256);
     run_shaped<0>("K loop: no loads, 1 WG/CU", out, w, e0, e1, 256);
+    {
+        float* ws;
+        CK(hipMalloc(&ws, (size_t)512 * 64 * 256 * 4));
+        for (int rep = 0; rep < 2; ++rep) {
+            run_shaped_t<2, 2, 0>("tile 64x64  (2 A + 2 B per block)", out, w, ws, e0, e1, 512);
+            run_shaped_t<1, 4, 0>("tile 32x128 (1 A + 4 B per block)", out, w, ws, e0, e1, 512);
+            run_shaped_t<2, 2, 1>("tile 64x64  + copy in the first burst", out, w, ws, e0, e1, 512);
+            run_shaped_t<2, 2, 2>("tile 64x64  + copy in the second burst", out, w, ws, e0, e1, 512);
+            run_shaped_t<2, 2, 3>("tile 64x64  + store first, read second", out, w, ws, e0, e1, 512);
+            run_shaped_t<1, 4, 1>("tile 32x128 + copy in the first burst", out, w, ws, e0, e1, 512);
+        }
+        CK(hipFree(ws));
+    }
     run_layered<15>("layered 64-row: all, buffer loads, 2 WG/CU", out, w, e0, e1, 512);
     run_layered<8>("layered 64-row: plain, buffer loads", out, w, e0, e1, 512);
     run_layered32<7>("layered 32-row tiles: all, 4 WG/CU", out, w, e0, e1, 1024);
