@@ -29,11 +29,15 @@ NERF_HD void nerf_sincosf_bounded(float x, float* sn, float* cs) {
     float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
     pc = fmaf(pc, z, 4.166664568298827e-2f);
     pc = fmaf(pc, z * z, fmaf(-0.5f, z, 1.0f));
-    const int q = (int)kf & 3;
-    const float s0 = (q & 1) ? pc : ps;
-    const float c0 = (q & 1) ? ps : pc;
-    *sn = (q & 2) ? -s0 : s0;
-    *cs = ((q + 1) & 2) ? -c0 : c0;
+    // quadrant q = kf mod 4: odd q swaps the two, sin changes sign for q in {2, 3}, cos for q in {1, 2}
+    // (bit 1 of q, and bit 1 xor bit 0, moved to the sign position and xor-ed in: no compares)
+    const unsigned q = (unsigned)(int)kf;
+    const float s0 = (q & 1u) ? pc : ps;
+    const float c0 = (q & 1u) ? ps : pc;
+    const unsigned sflip = (q << 30) & 0x80000000u;
+    const unsigned cflip = ((q << 30) ^ (q << 31)) & 0x80000000u;
+    *sn = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s0) ^ sflip);
+    *cs = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c0) ^ cflip);
 }
 
 NERF_HD void nerf_sincosf(float x, float* sn, float* cs) {
