@@ -705,6 +705,27 @@ def test_sample_pdf_indices_bit_exact(hip):
     assert (cdf_gpu.cpu() - cdf).abs().max() <= 2e-6
 
 
+@pytest.mark.parametrize("R,B,N", [(5, 1, 7), (9, 130, 200), (3, 2100, 50)])
+def test_sample_pdf_row_lengths(hip, R, B, N):
+    """Short, mid-sized and very long CDF rows (the last one takes the kernel that searches in global memory instead
+    of LDS): indices against searchsorted on the same CDF, samples against the oracle's interpolation."""
+    g = torch.Generator().manual_seed(B)
+    bins = torch.sort(torch.rand(R, B + 1, generator=g) * 4 + 2, dim=1).values
+    w = torch.rand(R, B, generator=g) ** 3
+    u = torch.rand(R, N, generator=g)
+    cdf = hip.weights_to_cdf(w.to(DEV))
+    s, idx = hip.sample_pdf(bins.to(DEV), cdf, u.to(DEV))
+    idx_ref = torch.searchsorted(cdf.cpu().contiguous(), u, right=True)
+    assert torch.equal(idx.cpu().long(), idx_ref)
+    c = cdf.cpu()
+    below, above = (idx_ref - 1).clamp(min=0), idx_ref.clamp(max=B)
+    c0, c1 = c.gather(1, below), c.gather(1, above)
+    den = c1 - c0
+    den = torch.where(den < 1e-5, torch.ones_like(den), den)
+    ref = bins.gather(1, below) + (u - c0) / den * (bins.gather(1, above) - bins.gather(1, below))
+    assert torch.equal(s.cpu(), ref)
+
+
 def test_merge_samples_sorted_union(hip):
     g = torch.Generator().manual_seed(8)
     for R, Sc, Sf in [(130, 64, 128), (5, 7, 0 + 3), (33, 100, 411), (4, 512, 512), (3, 3, 1021), (2, 1, 64), (6, 90, 200)]:
