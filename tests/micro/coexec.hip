@@ -1,0 +1,89 @@
+// Do VALU instructions of one wave overlap with fp32 MFMAs of another wave on the same SIMD, and how many VALU
+// instructions can a wave put between its own MFMAs for free?  (Diagnostic for the epilogue / encoding phases of the
+// fused MLP kernels, which run beside the co-resident workgroup's MFMA loops.)
+//   hipcc -O3 --offload-arch=gfx950 -o coexec coexec.hip && ./coexec
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+// 8 waves per workgroup, one workgroup per CU: waves 0-3 (one per SIMD) run MFMAs when ROLE & 1, waves 4-7 run
+// independent FMA chains when ROLE & 2.
+template <int ROLE>
+__global__ __launch_bounds__(512, 1) void roles(float* out, int mfma_iters, int valu_iters, float x) {
+    const int wave = threadIdx.x >> 6;
+    float s = 0.f;
+    if (wave < 4) {
+        if (ROLE & 1) {
+            f32x16 acc[4];
+            for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+            const float a = x * threadIdx.x, b = x + threadIdx.x;
+            for (int it = 0; it < mfma_iters; ++it)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u & 3], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) s += acc[i][k];
+        }
+    } else if (ROLE & 2) {
+        float v[8];
+        for (int i = 0; i < 8; ++i) v[i] = x * (threadIdx.x + i);
+        for (int it = 0; it < valu_iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 64; ++u) v[u & 7] = __builtin_fmaf(v[u & 7], x, 1.0f);
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+// one wave per SIMD; NV independent FMAs after every MFMA of the same wave
+template <int NV>
+__global__ __launch_bounds__(256, 1) void interleaved(float* out, int iters, float x) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = x * (threadIdx.x + i);
+    const float a = x * threadIdx.x, b = x + threadIdx.x;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u & 3], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j & 7] = __builtin_fmaf(v[j & 7], x, 1.0f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) s += acc[i][k];
+    for (int i = 0; i < 8; ++i) s += v[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <typename F>
+float timed(F launch) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    launch();
+    hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+int main() {
+    float* out;
+    CK(hipMalloc(&out, 256 * 512 * 4));
+    const int mi = 20000, vi = 20000;   // 320,000 MFMAs (64 cycles each) / 1,280,000 FMAs (4 cycles each) per wave: 20.5 M cycles each
+    const float tm = timed([&] { roles<1><<<256, 512>>>(out, mi, vi, 1e-3f); });
+    const float tv = timed([&] { roles<2><<<256, 512>>>(out, mi, vi, 1e-3f); });
+    const float tb = timed([&] { roles<3><<<256, 512>>>(out, mi, vi, 1e-3f); });
+    printf("MFMA waves alone %.3f ms, VALU waves alone %.3f ms, both on every SIMD %.3f ms (sum %.3f, max %.3f)\n", tm, tv, tb, tm + tv,
+           tm > tv ? tm : tv);
+    const float tb2 = timed([&] { roles<3><<<256, 512>>>(out, mi, vi / 4, 1e-3f); });
+    printf("both, a quarter of the VALU work: %.3f ms\n", tb2);
+    const int it = 20000;
+    const float t0 = timed([&] { interleaved<0><<<256, 256>>>(out, it, 1e-3f); });
+    printf("same wave: MFMA only %.3f ms\n", t0);
+    printf("same wave: + 2 FMA per MFMA %.3f ms\n", timed([&] { interleaved<2><<<256, 256>>>(out, it, 1e-3f); }));
+    printf("same wave: + 4 FMA per MFMA %.3f ms\n", timed([&] { interleaved<4><<<256, 256>>>(out, it, 1e-3f); }));
+    printf("same wave: + 8 FMA per MFMA %.3f ms\n", timed([&] { interleaved<8><<<256, 256>>>(out, it, 1e-3f); }));
+    printf("same wave: + 12 FMA per MFMA %.3f ms\n", timed([&] { interleaved<12><<<256, 256>>>(out, it, 1e-3f); }));
+    printf("same wave: + 16 FMA per MFMA %.3f ms\n", timed([&] { interleaved<16><<<256, 256>>>(out, it, 1e-3f); }));
+    return 0;
+}
