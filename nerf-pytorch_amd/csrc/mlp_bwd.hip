@@ -80,10 +80,9 @@ __device__ __forceinline__ void dgrad_layer(float* act, const float* __restrict_
                                             const mask_t* __restrict__ mask_word = nullptr) {
     const int lane = tid & 63;
     f32x16 acc[MT][2];
-    init_bias<2>(acc, nullptr, ncol0, lane);
     mask_t bits = 0;
     if constexpr (MASK == 3) bits = *mask_word;  // one 8-byte load, in flight during the whole K loop
-    mma_layer<2, COPY_COLS>(act, timg, lay::H, kb_count, ncol0, lane, acc, gin, tid);
+    mma_layer<2, COPY_COLS, ACC_ZERO>(act, timg, lay::H, kb_count, ncol0, lane, acc, gin, tid);
     __syncthreads();
     bwd_epilogue<2, MASK, RANK1>(act, acc, ncol0, lane, hsrc, lay::H, dsig_s, sigw, bits);
     __syncthreads();

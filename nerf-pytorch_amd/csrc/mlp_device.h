@@ -58,6 +58,38 @@ __device__ __forceinline__ void mma_block(const f32x4 (&a)[MT], const f32x4 (&b)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
 }
 
+// How a K loop finds its accumulators: ACC_KEEP continues the sums of an earlier pass; ACC_ZERO / ACC_BIAS start
+// them in the first MFMA of every tile, whose C operand is the constant 0 or a 16-register tile holding the lane's
+// bias (one tile per column block, shared by the row blocks), instead of 16 register moves per accumulator tile
+// beforehand.  VALU instructions do not overlap the fp32 MFMAs of any wave on the same SIMD, so every move saved
+// is matrix-pipe time.
+enum AccInit { ACC_KEEP = 0, ACC_ZERO = 1, ACC_BIAS = 2 };
+
+template <int NT, int INIT>
+__device__ __forceinline__ void mma_block_first(const f32x4 (&a)[MT], const f32x4 (&b)[NT], f32x16 (&acc)[MT][NT],
+                                                const float (&bias)[NT]) {
+    static_assert(INIT == ACC_ZERO || INIT == ACC_BIAS, "fresh accumulators only");
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        if constexpr (INIT == ACC_ZERO) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][0], b[ni][0], zero, 0, 0, 0);
+        } else {
+            const f32x16 btile = splat16(bias[ni]);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][0], b[ni][0], btile, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+}
+
 // Global operands of the K loops go through buffer instructions: the resource (base, size) lives in
 // SGPRs, the per-lane part of the address is ONE 32-bit VGPR that never changes, and the K block
 // advances in the scalar offset.  Measured on the K loop alone: two global_load_dwordx4 (64-bit
@@ -92,10 +124,13 @@ __device__ __forceinline__ void load_a(const float* a_ptr, int kb, f32x4 (&a)[MT
 // iteration stores).  The piece is read from LDS one iteration ahead and stored right after the weight
 // loads of the odd block: vmcnt retires in order, so the first wait that covers the store is the one
 // for the weight loads issued a whole MFMA block later, and no wave ever sits on a store acknowledgement.
-template <int NT, int COPY_COLS = 0>
+template <int NT, int COPY_COLS = 0, int INIT = ACC_KEEP>
 __device__ __forceinline__ void mma_layer(const float* act, const float* __restrict__ img, int n_img, int kb_count,
                                           int ncol0, int lane, f32x16 (&acc)[MT][NT], float* __restrict__ gcopy = nullptr,
-                                          int tid = 0) {
+                                          int tid = 0, const float* __restrict__ bias = nullptr) {
+    float bias_v[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) bias_v[ni] = (INIT == ACC_BIAS) ? bias[ncol0 + 32 * ni + (lane & 31)] : 0.0f;
     const int r = lane & 31, h = lane >> 5;
     const float* a_ptr = act + r * LDA + 4 * h;
     const int kb_bytes = n_img * 32;                                        // one K block of the image
@@ -135,7 +170,12 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
                 piece = *reinterpret_cast<const f32x4*>(csrc);
         }
         __builtin_amdgcn_sched_barrier(0);
-        mma_block<NT>(a0, b0, acc);
+        if constexpr (INIT != ACC_KEEP) {
+            if (kb == 0) mma_block_first<NT, INIT>(a0, b0, acc, bias_v);
+            else mma_block<NT>(a0, b0, acc);
+        } else {
+            mma_block<NT>(a0, b0, acc);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const int kn = min(kb + 2, last);  // clamped: the tail prefetch re-reads the last block
         load_b<NT>(b_rsrc, b_voff, kn, kb_bytes, b0);
@@ -197,9 +237,12 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], 
                 if constexpr (ACT == ACT_RELU) {
                     v = fmaxf(v, 0.0f);
                     if constexpr (NT == 2) {
+                        // 0 - v is negative exactly when v > 0 (and +0 for both zeros): its sign bit is shifted into
+                        // the word, so element e = (mi*NT + ni)*16 + g ends up at bit 31 - (e & 31) of word e >> 5
                         const int bit = (mi * NT + ni) * 16 + g;
-                        if (bit < 32) mlo |= (v > 0.0f) ? (1u << (bit & 31)) : 0u;
-                        else mhi |= (v > 0.0f) ? (1u << (bit & 31)) : 0u;
+                        const unsigned t = __builtin_bit_cast(unsigned, 0.0f - v);
+                        if (bit < 32) mlo = __builtin_amdgcn_alignbit(mlo, t, 31);
+                        else mhi = __builtin_amdgcn_alignbit(mhi, t, 31);
                     }
                 }
                 if constexpr (ACT == ACT_SIN) {
@@ -285,8 +328,9 @@ __device__ __forceinline__ void bwd_epilogue(float* act, f32x16 (&acc)[MT][NT], 
                 if constexpr (MASK == 1) v = stored(mi, ni, g) > 0.0f ? v : 0.0f;
                 if constexpr (MASK == 2) v = v * dpiece[g >> 2][g & 3];
                 if constexpr (MASK == 3) {
-                    const int bit = (mi * NT + ni) * 16 + g;
-                    v = (((bit < 32 ? blo : bhi) >> (bit & 31)) & 1u) ? v : 0.0f;
+                    const int bit = (mi * NT + ni) * 16 + g;       // at bit 31 - (bit & 31) of its word (fwd_epilogue)
+                    const int keep = __builtin_amdgcn_sbfe((int)(bit < 32 ? blo : bhi), 31 - (bit & 31), 1);   // 0 or all ones
+                    v = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
                 }
                 act[row * LDA + col] = v;
             }

@@ -295,8 +295,7 @@ __device__ __forceinline__ void hidden_layer(float* act, const float* __restrict
 #define LAYER_STAMP(i) ((void)0)
 #endif
     LAYER_STAMP(0);
-    init_bias<2>(acc, bias, ncol0, lane);
-    mma_layer<2, TRAIN ? IN_COLS : 0>(act, img, lay::H, IN_COLS / 8, ncol0, lane, acc, gin, tid);
+    mma_layer<2, TRAIN ? IN_COLS : 0, ACC_BIAS>(act, img, lay::H, IN_COLS / 8, ncol0, lane, acc, gin, tid, bias);
     if constexpr (TRAIN) {
         if (gmask_in) *gmask_in = *mask;   // ReLU mask word of the input tile's layer, kept in registers until now
     }
@@ -366,8 +365,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
     // L5: [h4 | pe] in two passes over the same accumulators
     {
         f32x16 acc[MT][2];
-        init_bias<2>(acc, pk + BIAS + 5 * H, ncol0, lane);
-        mma_layer<2, TRAIN ? H : 0>(act, pk + F_L5A, H, H / 8, ncol0, lane, acc, wsp(WS_H + 4 * (size_t)H, H), tid);
+        mma_layer<2, TRAIN ? H : 0, ACC_BIAS>(act, pk + F_L5A, H, H / 8, ncol0, lane, acc, wsp(WS_H + 4 * (size_t)H, H), tid,
+                                              pk + BIAS + 5 * H);
         if constexpr (TRAIN) *mskp(4) = mask;
         __syncthreads();
         DIAG_STAMP(8);
@@ -390,8 +389,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
     // L9: 256 feature columns on MFMA, density column on the VALU
     {
         f32x16 acc[MT][2];
-        init_bias<2>(acc, pk + BIAS + 9 * H, ncol0, lane);
-        mma_layer<2, TRAIN ? H : 0>(act, pk + F_L9, H, H / 8, ncol0, lane, acc, wsp(WS_H + 8 * (size_t)H, H), tid);
+        mma_layer<2, TRAIN ? H : 0, ACC_BIAS>(act, pk + F_L9, H, H / 8, ncol0, lane, acc, wsp(WS_H + 8 * (size_t)H, H), tid,
+                                              pk + BIAS + 9 * H);
         const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
         if constexpr (TRAIN) *mskp(8) = mask;
         if (tid % TPS == 0) {
@@ -407,8 +406,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
     {
         const int nc = wave * 32;
         f32x16 acc[MT][1];
-        init_bias<1>(acc, pk + BIAS10, nc, lane);
-        mma_layer<1, TRAIN ? H : 0>(act, pk + F_L10A, HH, H / 8, nc, lane, acc, wsp(WS_F, H), tid);
+        mma_layer<1, TRAIN ? H : 0, ACC_BIAS>(act, pk + F_L10A, HH, H / 8, nc, lane, acc, wsp(WS_F, H), tid, pk + BIAS10);
         __syncthreads();
         DIAG_STAMP(15);
         encode_de(act, xin, tid);
@@ -477,8 +475,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void siren_fwd_kernel(FwdArgs a) {
     // feature_remap on MFMA, density branch on the VALU (both read h7)
     {
         f32x16 acc[MT][2];
-        init_bias<2>(acc, pk + BIAS + 8 * H, ncol0, lane);
-        mma_layer<2, TRAIN ? H : 0>(act, pk + F_FEAT, H, H / 8, ncol0, lane, acc, wsp(WS_H + 7 * (size_t)H, H), tid);
+        mma_layer<2, TRAIN ? H : 0, ACC_BIAS>(act, pk + F_FEAT, H, H / 8, ncol0, lane, acc, wsp(WS_H + 7 * (size_t)H, H), tid,
+                                              pk + BIAS + 8 * H);
         const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
         if (tid % TPS == 0) {
             sraw_s[tid / TPS] = s;
@@ -491,8 +489,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void siren_fwd_kernel(FwdArgs a) {
     {
         const int nc = wave * 32;
         f32x16 acc[MT][1];
-        init_bias<1>(acc, pk + BIAS_RGB, nc, lane);
-        mma_layer<1, TRAIN ? H : 0>(act, pk + F_RGBA, HH, H / 8, nc, lane, acc, wsp(WS_F, H), tid);
+        mma_layer<1, TRAIN ? H : 0, ACC_BIAS>(act, pk + F_RGBA, HH, H / 8, nc, lane, acc, wsp(WS_F, H), tid, pk + BIAS_RGB);
         __syncthreads();
         encode_de(act, xin, tid);
         __syncthreads();
