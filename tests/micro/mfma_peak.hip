@@ -208,9 +208,21 @@ __global__ __launch_bounds__(256, 2) void layered(float* out, const float* __res
         }
         if (MODE & 1) {
             __syncthreads();
-            for (int mi = 0; mi < 2; ++mi) for (int ni = 0; ni < 2; ++ni) for (int g = 0; g < 16; ++g) {
-                int row = 32 * mi + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5), col = wave * 64 + 32 * ni + (lane & 31);
-                lds[row * 260 + col] = fmaxf(acc[mi][ni][g], 0.f) * 1e-3f;
+            if (MODE & 16) {        // the same 64 values as 16 ds_write_b128 (what a transposed accumulator tile would allow)
+                for (int mi = 0; mi < 2; ++mi) for (int ni = 0; ni < 2; ++ni) for (int g4 = 0; g4 < 4; ++g4) {
+                    int row = 32 * mi + (lane & 31), col = wave * 64 + 32 * ni + 8 * g4 + 4 * (lane >> 5);
+                    f32x4 v;
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[mi][ni][4 * g4 + k], 0.f) * 1e-3f;
+                    *reinterpret_cast<f32x4*>(lds + row * 260 + col) = v;
+                }
+            } else if (MODE & 32) { // the VALU work without the LDS writes
+                for (int mi = 0; mi < 2; ++mi) for (int ni = 0; ni < 2; ++ni) for (int g = 0; g < 16; ++g)
+                    s += fmaxf(acc[mi][ni][g], 0.f) * 1e-3f;
+            } else {
+                for (int mi = 0; mi < 2; ++mi) for (int ni = 0; ni < 2; ++ni) for (int g = 0; g < 16; ++g) {
+                    int row = 32 * mi + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5), col = wave * 64 + 32 * ni + (lane & 31);
+                    lds[row * 260 + col] = fmaxf(acc[mi][ni][g], 0.f) * 1e-3f;
+                }
             }
             __syncthreads();
         } else {
@@ -439,6 +451,12 @@ int main() {
             run_shaped_t<1, 4, 1>("tile 32x128 + copy in the first burst", out, w, ws, e0, e1, 512);
         }
         CK(hipFree(ws));
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        run_layered<15>("layered: 64 ds_write_b32 epilogue", out, w, e0, e1, 512);
+        run_layered<15 + 16>("layered: 16 ds_write_b128 epilogue", out, w, e0, e1, 512);
+        run_layered<15 + 32>("layered: epilogue VALU only, no LDS writes", out, w, e0, e1, 512);
+        run_layered<14>("layered: no epilogue, no barriers", out, w, e0, e1, 512);
     }
     run_layered<15>("layered 64-row: all, buffer loads, 2 WG/CU", out, w, e0, e1, 512);
     run_layered<8>("layered 64-row: plain, buffer loads", out, w, e0, e1, 512);
