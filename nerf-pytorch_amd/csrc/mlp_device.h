@@ -154,7 +154,12 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
     }
     load_b<NT>(b_rsrc, b_voff, 0, kb_bytes, b0);
     load_a(a_ptr, 0, a0);
-#pragma unroll 1
+    // VALU instructions between a wave's MFMAs cost 10-14 cycles of matrix-pipe time each (LDS, buffer and scalar
+    // instructions cost none), so the loop keeps ONE address register for the A fragments, advanced once per trip with the
+    // other blocks at immediate offsets; the last trip reads 8 columns past the K range (inside the LDS allocation,
+    // never used).  Two trips are unrolled so that the copy's LDS address also moves once per two trips.
+    const float* a_cur = a_ptr;
+#pragma unroll 2
     for (int kb = 0; kb < kb_count; kb += 2) {
         load_b<NT>(b_rsrc, b_voff, kb + 1, kb_bytes, b1);
         if constexpr (COPY_COLS != 0) {
@@ -164,7 +169,7 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
                 csrc += RSTEP * LDA;
             }
         }
-        load_a(a_ptr, kb + 1, a1);
+        load_a(a_cur, 1, a1);
         if constexpr (COPY_COLS != 0) {
             if ((SE == 1 || (((kb >> 1) + 1) & (SE - 1)) == 0) && kb + 2 < kb_count)
                 piece = *reinterpret_cast<const f32x4*>(csrc);
@@ -177,9 +182,10 @@ __device__ __forceinline__ void mma_layer(const float* act, const float* __restr
             mma_block<NT>(a0, b0, acc);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const int kn = min(kb + 2, last);  // clamped: the tail prefetch re-reads the last block
+        const int kn = min(kb + 2, last);  // clamped: the tail prefetch re-reads the last block of the image
         load_b<NT>(b_rsrc, b_voff, kn, kb_bytes, b0);
-        load_a(a_ptr, kn, a0);
+        load_a(a_cur, 2, a0);
+        a_cur += 16;
         __builtin_amdgcn_sched_barrier(0);
         mma_block<NT>(a1, b1, acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -235,7 +241,9 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], 
                 float v = acc[mi][ni][g];
                 float c = 0.f;
                 if constexpr (ACT == ACT_RELU) {
-                    v = fmaxf(v, 0.0f);
+                    // max(v, 0) as ONE instruction: fmaxf (and every intrinsic the compiler folds back into it) puts a
+                    // canonicalising v_max_f32 v, v, v in front, and VALU instructions are matrix-pipe time here
+                    asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(v));
                     if constexpr (NT == 2) {
                         // 0 - v is negative exactly when v > 0 (and +0 for both zeros): its sign bit is shifted into
                         // the word, so element e = (mi*NT + ni)*16 + g ends up at bit 31 - (e & 31) of word e >> 5

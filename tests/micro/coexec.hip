@@ -56,6 +56,38 @@ __global__ __launch_bounds__(256, 1) void interleaved(float* out, int iters, flo
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// one wave per SIMD; N instructions of one kind after every MFMA of the same wave
+//   KIND 0: v_mov_b32 (VALU)   1: s_add_u32 (SALU)   2: ds_read_b32 (LDS)   3: ds_read_b128   4: ds_write_b32
+template <int KIND, int N>
+__global__ __launch_bounds__(256, 1) void between(float* out, int iters, float x) {
+    __shared__ __attribute__((aligned(16))) float lds[256 * 4 + 64];
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+    for (int i = threadIdx.x; i < 256 * 4 + 64; i += 256) lds[i] = x * i;
+    __syncthreads();
+    const float a = x * threadIdx.x, b = x + threadIdx.x;
+    const unsigned lds_addr = (unsigned)(size_t)(lds + threadIdx.x * 4);
+    unsigned sreg = 1;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u & 3], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (KIND == 0) asm volatile("v_mov_b32 v200, %0" :: "v"(a) : "v200");
+                if (KIND == 1) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sreg));
+                if (KIND == 2) asm volatile("ds_read_b32 v200, %0" :: "v"(lds_addr) : "v200");
+                if (KIND == 3) asm volatile("ds_read_b128 v[200:203], %0" :: "v"(lds_addr) : "v200", "v201", "v202", "v203");
+                if (KIND == 4) asm volatile("ds_write_b32 %0, %1" :: "v"(lds_addr), "v"(a));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    float s = (float)sreg;
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) s += acc[i][k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <typename F>
 float timed(F launch) {
     hipEvent_t e0, e1;
@@ -85,5 +117,12 @@ int main() {
     printf("same wave: + 8 FMA per MFMA %.3f ms\n", timed([&] { interleaved<8><<<256, 256>>>(out, it, 1e-3f); }));
     printf("same wave: + 12 FMA per MFMA %.3f ms\n", timed([&] { interleaved<12><<<256, 256>>>(out, it, 1e-3f); }));
     printf("same wave: + 16 FMA per MFMA %.3f ms\n", timed([&] { interleaved<16><<<256, 256>>>(out, it, 1e-3f); }));
+    const char* kinds[5] = {"v_mov_b32", "s_add_u32", "ds_read_b32", "ds_read_b128", "ds_write_b32"};
+#define ROW(K)                                                                                              \
+    printf("same wave, %-12s per MFMA: x1 %.3f  x2 %.3f  x4 %.3f ms (MFMA only %.3f)\n", kinds[K],           \
+           timed([&] { between<K, 1><<<256, 256>>>(out, it, 1e-3f); }),                                      \
+           timed([&] { between<K, 2><<<256, 256>>>(out, it, 1e-3f); }),                                      \
+           timed([&] { between<K, 4><<<256, 256>>>(out, it, 1e-3f); }), t0)
+    ROW(0); ROW(1); ROW(2); ROW(3); ROW(4);
     return 0;
 }
