@@ -200,20 +200,25 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
     // [32][NW] of dY followed by [32][KW] of X; 16-byte piece v of either part lands at byte 16*v of
     // that part, which is what global_load_lds requires of a wave: a wave-uniform LDS base plus
     // 16 bytes per lane (the per-lane SOURCE address follows the row pitch of the tensor in HBM)
-    auto stage_part = [&](const float* src, int ld, auto width, float* dst) {
+    // Buffer form of the LDS-DMA: the resource covers this workgroup's rows, the chunk advances in the scalar offset and the
+    // 32-bit lane offset never changes -- no vector instructions per chunk (they would cost matrix-pipe time).
+    const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.dY + (size_t)c0 * 32 * a.ldy, (unsigned)((size_t)(c1 - c0) * 32 * a.ldy * 4));
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(a.X + (size_t)c0 * 32 * a.ldx, (unsigned)((size_t)(c1 - c0) * 32 * a.ldx * 4));
+    auto stage_part = [&](__amdgpu_buffer_rsrc_t rsrc, int chunk_rel, int ld, auto width, float* dst) {
         constexpr int W4 = decltype(width)::value / 4, TOT = 32 * W4;  // TOT is a multiple of 64
+        const int soff = chunk_rel * 32 * ld * 4;
 #pragma unroll
         for (int i = 0; i < (TOT + 511) / 512; ++i) {
             const int v = tid + i * 512;
+            const int voff = ((v / W4) * ld + 4 * (v % W4)) * 4;
             if (v < TOT)  // whole waves are in or out
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + (size_t)(v / W4) * ld + 4 * (v % W4)),
-                    (__attribute__((address_space(3))) void*)(dst + 4 * (64 * wave + i * 512)), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 4 * (64 * wave + i * 512)),
+                                                     16, voff, soff, 0, 0);
         }
     };
     auto stage = [&](int chunk, float* buf) {
-        stage_part(a.dY + (size_t)chunk * 32 * a.ldy, a.ldy, std::integral_constant<int, NW>{}, buf);
-        stage_part(a.X + (size_t)chunk * 32 * a.ldx, a.ldx, std::integral_constant<int, KW>{}, buf + 32 * NW);
+        stage_part(y_rsrc, chunk - c0, a.ldy, std::integral_constant<int, NW>{}, buf);
+        stage_part(x_rsrc, chunk - c0, a.ldx, std::integral_constant<int, KW>{}, buf + 32 * NW);
         if (RANK1 && tid < 32)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.q + (size_t)chunk * 32 + tid),
                                              (__attribute__((address_space(3))) void*)(buf + 32 * ROWF), 4, 0, 0);
