@@ -16,7 +16,11 @@
 // inlined code is ~100 instructions per call site.  For call sites whose argument is bounded by
 // construction: pre-activations of sine layers fed by sines (|z| <= sum|w| + |b|).
 NERF_HD void nerf_sincosf_bounded(float x, float* sn, float* cs) {
-    const float kf = rintf(x * 0.63661977236758134f);  // nearest multiple of pi/2
+    // nearest multiple of pi/2: adding 1.5 * 2^23 rounds to an integer (to nearest even, as rintf does) for
+    // |x * 2/pi| < 2^22 and leaves that integer in the low bits of the sum -- two additions that pair up into packed
+    // instructions, where a multiplication, rintf and a float -> int conversion are three, two of them unpackable
+    const float tm = fmaf(x, 0.63661977236758134f, 12582912.0f);   // one rounding, in every translation unit
+    const float kf = tm - 12582912.0f;
     // pi/2 = P1 + P2 + P3; P1 has 8 significant bits, so kf*P1 is exact for |kf| < 2^16
     float r = fmaf(-kf, 1.5703125f, x);
     r = fmaf(-kf, 4.837512969970703125e-4f, r);
@@ -30,14 +34,20 @@ NERF_HD void nerf_sincosf_bounded(float x, float* sn, float* cs) {
     pc = fmaf(pc, z, 4.166664568298827e-2f);
     pc = fmaf(pc, z * z, fmaf(-0.5f, z, 1.0f));
     // quadrant q = kf mod 4: odd q swaps the two, sin changes sign for q in {2, 3}, cos for q in {1, 2}
-    // (bit 1 of q, and bit 1 xor bit 0, moved to the sign position and xor-ed in: no compares)
-    const unsigned q = (unsigned)(int)kf;
-    const float s0 = (q & 1u) ? pc : ps;
-    const float c0 = (q & 1u) ? ps : pc;
-    const unsigned sflip = (q << 30) & 0x80000000u;
-    const unsigned cflip = ((q << 30) ^ (q << 31)) & 0x80000000u;
-    *sn = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s0) ^ sflip);
-    *cs = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c0) ^ cflip);
+    // (bit 1 of q, and bit 1 xor bit 0, moved to the sign position and xor-ed in: no compares beyond the swap's)
+    const unsigned q = __builtin_bit_cast(unsigned, tm);   // low bits = the integer
+    const unsigned b1 = q << 30, b0 = q << 31;             // bit 1 (and bit 0 below it) / bit 0 alone at the sign position
+    const bool odd = (int)b0 < 0;
+    const float s0 = odd ? pc : ps;
+    const float c0 = odd ? ps : pc;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // three-input bit operations: a ^ (b & c) and (a & b) ^ c
+    *sn = __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(unsigned, s0), b1, 0x80000000u, 0x78));
+    *cs = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c0) ^ __builtin_amdgcn_bitop3_b32(b1, 0x80000000u, b0, 0x6A));
+#else
+    *sn = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s0) ^ (b1 & 0x80000000u));
+    *cs = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c0) ^ ((b1 & 0x80000000u) ^ b0));
+#endif
 }
 
 NERF_HD void nerf_sincosf(float x, float* sn, float* cs) {
