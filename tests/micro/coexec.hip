@@ -88,6 +88,44 @@ __global__ __launch_bounds__(256, 1) void between(float* out, int iters, float x
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// waves 4-7 issue 16 independent instructions of one kind per iteration (fixed registers v200..v231); waves 0-3 run
+// MFMAs when WITH_MFMA.   KIND 0: v_fma_f32   1: v_pk_fma_f32   2: v_mov_b32   3: v_alignbit_b32   4: v_max_f32
+#define R16(OP) OP(200) OP(202) OP(204) OP(206) OP(208) OP(210) OP(212) OP(214) OP(216) OP(218) OP(220) OP(222) OP(224) OP(226) OP(228) OP(230)
+#define OP_FMA(r) "v_fma_f32 v" #r ", %0, %0, v" #r "\n\t"
+#define OP_PKFMA(r) "v_pk_fma_f32 v[" #r ":" #r "+1], %1, %1, v[" #r ":" #r "+1]\n\t"
+#define OP_MOV(r) "v_mov_b32 v" #r ", %0\n\t"
+#define OP_ALIGN(r) "v_alignbit_b32 v" #r ", v" #r ", %0, 31\n\t"
+#define OP_MAX(r) "v_max_f32 v" #r ", 0, %0\n\t"
+#define CLOB "v200","v201","v202","v203","v204","v205","v206","v207","v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231"
+template <int KIND, bool WITH_MFMA>
+__global__ __launch_bounds__(512, 1) void beside(float* out, int mfma_iters, int valu_iters, float x) {
+    const int wave = threadIdx.x >> 6;
+    float s = 0.f;
+    if (wave < 4) {
+        if (WITH_MFMA) {
+            f32x16 acc[4];
+            for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+            const float a = x * threadIdx.x, b = x + threadIdx.x;
+            for (int it = 0; it < mfma_iters; ++it)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u & 3], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) s += acc[i][k];
+        }
+    } else {
+        const float a = x * threadIdx.x;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 a2 = {a, a};
+        for (int it = 0; it < valu_iters; ++it) {
+            if (KIND == 0) asm volatile(R16(OP_FMA) :: "v"(a), "v"(a2) : CLOB);
+            if (KIND == 1) asm volatile(R16(OP_PKFMA) :: "v"(a), "v"(a2) : CLOB);
+            if (KIND == 2) asm volatile(R16(OP_MOV) :: "v"(a), "v"(a2) : CLOB);
+            if (KIND == 3) asm volatile(R16(OP_ALIGN) :: "v"(a), "v"(a2) : CLOB);
+            if (KIND == 4) asm volatile(R16(OP_MAX) :: "v"(a), "v"(a2) : CLOB);
+        }
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 template <typename F>
 float timed(F launch) {
     hipEvent_t e0, e1;
@@ -117,6 +155,19 @@ int main() {
     printf("same wave: + 8 FMA per MFMA %.3f ms\n", timed([&] { interleaved<8><<<256, 256>>>(out, it, 1e-3f); }));
     printf("same wave: + 12 FMA per MFMA %.3f ms\n", timed([&] { interleaved<12><<<256, 256>>>(out, it, 1e-3f); }));
     printf("same wave: + 16 FMA per MFMA %.3f ms\n", timed([&] { interleaved<16><<<256, 256>>>(out, it, 1e-3f); }));
+    {
+        const char* names[5] = {"v_fma_f32", "v_pk_fma_f32", "v_mov_b32", "v_alignbit_b32", "v_max_f32"};
+        const int vit = 40000;     // 640,000 instructions per wave
+        const float m0 = timed([&] { beside<0, true><<<256, 512>>>(out, mi, 0, 1e-3f); });
+#define BROW(K)                                                                                                        \
+        {                                                                                                              \
+            const float alone = timed([&] { beside<K, false><<<256, 512>>>(out, mi, vit, 1e-3f); });                   \
+            const float both = timed([&] { beside<K, true><<<256, 512>>>(out, mi, vit, 1e-3f); });                     \
+            printf("%-15s alone %.3f ms = %.1f cycles each; beside MFMA waves (%.3f ms alone): %.3f ms = +%.1f cycles each\n", names[K], alone, \
+                   alone * 2.4e6 / (16.0 * vit), m0, both, (both - m0) * 2.4e6 / (16.0 * vit));                         \
+        }
+        BROW(0) BROW(1) BROW(2) BROW(3) BROW(4)
+    }
     const char* kinds[5] = {"v_mov_b32", "s_add_u32", "ds_read_b32", "ds_read_b128", "ds_write_b32"};
 #define ROW(K)                                                                                              \
     printf("same wave, %-12s per MFMA: x1 %.3f  x2 %.3f  x4 %.3f ms (MFMA only %.3f)\n", kinds[K],           \
