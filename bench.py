@@ -244,8 +244,10 @@ def main():
         host_sync_for_gloo()
         if hier:
             u = parallel.shared_uniform(args.coarse, dev, ugen)
+            # inference mode renders the fine image only (what eval.py does): the coarse pass stops at the densities
             rc, rf = render_nerf_hierarchical(models[0], models[1], o, d, near, far, args.coarse, args.fine, device=dev,
-                                              white_background=True, chunk_size=max(B, 8192), u=[u])
+                                              white_background=True, chunk_size=max(B, 8192), u=[u],
+                                              coarse_rgb=args.mode == "train")
             return rc, rf
         u = parallel.shared_uniform(S, dev, ugen)
         return (render_nerf(model, o, d, near, far, num_samples=S, device=dev, white_background=True,
@@ -308,6 +310,8 @@ def main():
                      ("mlp_bwd_weights", fl["wgrad"], "per-layer weight-gradient GEMMs + one reduction (launch group)")]
         else:
             specs = [("mlp_fwd_infer", fl["fwd"], "fused sample+encode+MLP forward (inference)"),
+                     ("mlp_fwd_infer_density", 2 * 556800, "the same pass stopped after the density row (coarse pass of a "
+                                                           "hierarchical render; no feature layer, rgb layers or head)"),
                      ("mlp_fwd_infer_bf16", fl["fwd"], "bf16 opt-in: register-chain encode+MLP forward (inference)")]
         table = {}
         for base, flop_per_sample, desc in specs:
@@ -375,7 +379,9 @@ def main():
         res = {
             "metric": (f"train rays/sec (fwd+bwd+Adam, {args.coarse}+{args.fine} samples/ray)" if hier else
                        f"train rays/sec (fwd+bwd+Adam, {S} samples/ray single pass)") if args.mode == "train"
-                      else f"inference rays/sec ({S} MLP evaluations/ray)",
+                      else (f"inference rays/sec ({S} MLP evaluations/ray"
+                            + (f", the {args.coarse} coarse ones density only)" if hier and args.model == "nerf"
+                               and args.precision != "bf16" else ")")),
             "value": world * B * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",

@@ -71,7 +71,8 @@ int nerf_posenc_bwd(const float* x, const float* grad_out, int64_t M, int D, int
  * weights [R,S] (= T_excl(1-alpha)*alpha), depth [R] (= sum w*t, needs t [S]; no reference
  * counterpart), acc [R] (= sum w).  One ray per wavefront; 1 <= S <= 1024.
  * per_ray != 0: deltas and t are [R,S] (every ray has its own sample depths, as after
- * hierarchical re-sampling) instead of one shared [S] vector. */
+ * hierarchical re-sampling) instead of one shared [S] vector.
+ * colors == NULL together with rgb == NULL: weights only (weights must then be given). */
 int nerf_composite_fwd(const float* colors, const float* densities, const float* deltas, const float* t,
                        int64_t R, int S, int per_ray, int white_background, float* rgb, float* weights,
                        float* depth, float* acc, void* stream);
@@ -119,7 +120,10 @@ int nerf_mlp_pack(int model, const float* const* params, float* packed, void* st
  *                   M = R*S; sample m belongs to ray m/S and the position is generated and
  *                   normalised in registers as nerf/rendering.py:59-62,82 would (never
  *                   materialised in HBM).
- * Outputs: colors [M,3], density [M].
+ * Outputs: colors [M,3], density [M].  colors == NULL (NERF_MODEL_NERF, workspace == NULL only): the
+ * pass stops after the density row and writes densities only -- the coarse pass of a hierarchical
+ * render without gradients needs nothing else (no counterpart in the reference, whose renderer is
+ * single pass).
  * workspace: NULL for inference; else nerf_mlp_fwd_workspace_floats(model, M) floats that
  * nerf_mlp_bwd reads. */
 int nerf_mlp_fwd(int model, const float* packed, int64_t M, const float* points, const float* dirs,

@@ -50,7 +50,7 @@ __device__ __forceinline__ void load_ray(const float* __restrict__ colors, const
         float flat[EPL * 3];
 #pragma unroll
         for (int q = 0; q < EPL * 3 / 4; ++q) {
-            const f32x4 cv = cp[q];
+            const f32x4 cv = colors ? cp[q] : f32x4{0.f, 0.f, 0.f, 0.f};   // colors == NULL: weights-only call
 #pragma unroll
             for (int k = 0; k < 4; ++k) flat[4 * q + k] = cv[k];
         }
@@ -66,7 +66,7 @@ __device__ __forceinline__ void load_ray(const float* __restrict__ colors, const
             sig[e] = ok ? dens[r * S + s] : 0.0f;   // sigma = 0 -> alpha = 0, beta = 1: identity
             dl[e] = ok ? deltas[s] : 0.0f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) col[e][c] = ok ? colors[(r * S + s) * 3 + c] : 0.0f;
+            for (int c = 0; c < 3; ++c) col[e][c] = (ok && colors) ? colors[(r * S + s) * 3 + c] : 0.0f;
         }
     }
 }
@@ -139,9 +139,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_fwd_kernel(
     if (depth) sd = wave_sum(sd);
     if (lane == 0) {
         const float bg = white ? (1.0f - sw) : 0.0f;
-        rgb[r * 3 + 0] = sr + bg;
-        rgb[r * 3 + 1] = sg + bg;
-        rgb[r * 3 + 2] = sb + bg;
+        if (rgb) {
+            rgb[r * 3 + 0] = sr + bg;
+            rgb[r * 3 + 1] = sg + bg;
+            rgb[r * 3 + 2] = sb + bg;
+        }
         if (depth) depth[r] = sd;
         if (accout) accout[r] = sw;
     }
@@ -369,10 +371,10 @@ extern "C" int nerf_composite_fwd(const float* colors, const float* densities, c
                                   float* depth, float* acc, void* stream) {
     NERF_REQUIRE(R >= 0 && S >= 1 && S <= 1024, "nerf_composite_fwd: bad R=%lld S=%d (1..1024)", (long long)R, S);
     if (R == 0) return NERF_OK;
-    NERF_REQUIRE_PTR(colors);
     NERF_REQUIRE_PTR(densities);
     NERF_REQUIRE_PTR(deltas);
-    NERF_REQUIRE_PTR(rgb);
+    NERF_REQUIRE((colors != nullptr && rgb != nullptr) || (colors == nullptr && rgb == nullptr && weights != nullptr),
+                 "nerf_composite_fwd: colors and rgb go together; without them (weights only) the weights output is required");
     NERF_REQUIRE(depth == nullptr || t != nullptr, "nerf_composite_fwd: depth output needs t");
     NERF_REQUIRE(ceil_div64(R, kWavesPerBlock) < (1ll << 31), "nerf_composite_fwd: too many rays");
     hipStream_t st = (hipStream_t)stream;

@@ -308,8 +308,11 @@ __device__ __forceinline__ void hidden_layer(float* act, const float* __restrict
     LAYER_STAMP(4);
 }
 
-template <bool TRAIN>
+// DENSITY_ONLY (inference): stops after the density row of block2.8 -- the coarse pass of a hierarchical render only feeds
+// the re-sampling, which needs no colors (the feature layer, the 288 -> 128 layer and the head are 16 % of the network)
+template <bool TRAIN, bool DENSITY_ONLY = false>
 __global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
+    static_assert(!(TRAIN && DENSITY_ONLY), "the density-only pass is an inference variant");
     using namespace lay;
     using namespace lay::nerf;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -385,6 +388,12 @@ __global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
         hidden_layer<ACT_RELU, TRAIN, H>(act, pk + F_L6 + (size_t)(l - 6) * img(H, H), pk + BIAS + l * H, ncol0, tid,
                                          wsp(WS_H + (size_t)(l - 1) * H, H), nullptr, mskp(l - 1), &mask);
         DIAG_STAMP(5 + l);
+    }
+    if constexpr (DENSITY_ONLY) {
+        const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
+        const size_t m = m0 + tid / TPS;
+        if (tid % TPS == 0 && m < (size_t)a.M) a.density[m] = fmaxf(s, 0.0f);
+        return;
     }
     // L9: 256 feature columns on MFMA, density column on the VALU
     {
@@ -520,8 +529,9 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
     NERF_REQUIRE(M >= 0, "nerf_mlp_fwd: M=%lld < 0", (long long)M);
     if (M == 0) return NERF_OK;
     NERF_REQUIRE_PTR(packed);
-    NERF_REQUIRE_PTR(colors);
     NERF_REQUIRE_PTR(density);
+    NERF_REQUIRE(colors != nullptr || (model == NERF_MODEL_NERF && workspace == nullptr),
+                 "nerf_mlp_fwd: colors may be NULL (density only) for the NeRF model without a training workspace only");
     if (points) {
         NERF_REQUIRE_PTR(dirs);
     } else {
@@ -544,9 +554,12 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
         if (workspace) {
             if ((rc = nerf_set_lds(nerf_fwd_kernel<true>, FWD_LDS_BYTES))) return rc;
             nerf_fwd_kernel<true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
-        } else {
+        } else if (colors) {
             if ((rc = nerf_set_lds(nerf_fwd_kernel<false>, FWD_LDS_BYTES))) return rc;
             nerf_fwd_kernel<false><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+        } else {
+            if ((rc = nerf_set_lds(nerf_fwd_kernel<false, true>, FWD_LDS_BYTES))) return rc;
+            nerf_fwd_kernel<false, true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
         }
     } else {
         if (workspace) {

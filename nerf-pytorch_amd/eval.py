@@ -103,7 +103,7 @@ def main(argv=None):
     def render(o, d):
         if pair:
             return render_nerf_hierarchical(nets[0], nets[1], o, d, near, far, num_samples, num_fine, device=device,
-                                            white_background=True, chunk_size=chunk_size)[1]
+                                            white_background=True, chunk_size=chunk_size, coarse_rgb=False)[1]
         return render_nerf(nets[0], o, d, near, far, num_samples=num_samples, device=device, white_background=True,
                            chunk_size=chunk_size)
 

@@ -211,21 +211,23 @@ def posenc_bwd(x: torch.Tensor, grad_out: torch.Tensor, L: int) -> torch.Tensor:
 # --------------------------------------------------------------------------- compositing
 def composite_fwd(colors, densities, deltas, white: bool, t=None, want_weights=False, want_depth=False,
                   want_acc=False):
+    """colors=None: weights only (rgb comes back as None; want_weights is implied)."""
     R, S = densities.shape
     per_ray = deltas.dim() == 2
-    if colors.shape != (R, S, 3) or deltas.shape != ((R, S) if per_ray else (S,)) or \
+    if (colors is not None and colors.shape != (R, S, 3)) or deltas.shape != ((R, S) if per_ray else (S,)) or \
             (t is not None and t.shape != deltas.shape):
-        raise ValueError(f"composite: colors {tuple(colors.shape)} densities {tuple(densities.shape)} "
-                         f"deltas {tuple(deltas.shape)} do not agree")
+        raise ValueError(f"composite: colors {None if colors is None else tuple(colors.shape)} densities "
+                         f"{tuple(densities.shape)} deltas {tuple(deltas.shape)} do not agree")
     dev = densities.device
-    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    want_weights = want_weights or colors is None
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev) if colors is not None else None
     weights = torch.empty((R, S), dtype=torch.float32, device=dev) if want_weights else None
     depth = torch.empty((R,), dtype=torch.float32, device=dev) if want_depth else None
     acc = torch.empty((R,), dtype=torch.float32, device=dev) if want_acc else None
     if want_depth and t is None:
         raise ValueError("depth output needs t")
-    _check(lib.nerf_composite_fwd(_dev(colors, "colors"), _dev(densities, "densities"), _dev(deltas, "deltas"),
-                                  _opt(t, "t"), R, S, int(per_ray), int(bool(white)), _dev(rgb, "rgb"), _opt(weights, "weights"),
+    _check(lib.nerf_composite_fwd(_opt(colors, "colors"), _dev(densities, "densities"), _dev(deltas, "deltas"),
+                                  _opt(t, "t"), R, S, int(per_ray), int(bool(white)), _opt(rgb, "rgb"), _opt(weights, "weights"),
                                   _opt(depth, "depth"), _opt(acc, "acc"), _stream()), "nerf_composite_fwd")
     return rgb, weights, depth, acc
 
@@ -261,18 +263,21 @@ def mlp_pack(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Ten
 
 
 def mlp_fwd(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None, rays_o=None, rays_d=None, t=None,
-            S: int = 0, near: float = 0.0, far: float = 1.0, train: bool = False):
+            S: int = 0, near: float = 0.0, far: float = 1.0, train: bool = False, want_colors: bool = True):
+    """want_colors=False (NeRF model, inference only): the pass stops after the density row; colors come back as None."""
     dev = packed.device
-    colors = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    if not want_colors and (train or model != MODEL_NERF):
+        raise ValueError("the density-only pass is an inference variant of the NeRF model")
+    colors = torch.empty((M, 3), dtype=torch.float32, device=dev) if want_colors else None
     density = torch.empty((M,), dtype=torch.float32, device=dev)
     ws = None
     if train:
         ws = torch.empty(lib.nerf_mlp_fwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
-    ev = timers.start("mlp_fwd_train" if train else "mlp_fwd_infer", M)
+    ev = timers.start("mlp_fwd_train" if train else ("mlp_fwd_infer" if want_colors else "mlp_fwd_infer_density"), M)
     _check(lib.nerf_mlp_fwd(model, _dev(packed, "packed"), M, _opt(points, "points"), _opt(dirs, "dirs"),
                             _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S,
                             int(t is not None and t.dim() == 2), float(near), float(far),
-                            _dev(colors, "colors"), _dev(density, "density"), _opt(ws, "workspace"), _stream()),
+                            _opt(colors, "colors"), _dev(density, "density"), _opt(ws, "workspace"), _stream()),
            "nerf_mlp_fwd")
     timers.stop(ev)
     return colors, density, ws

@@ -149,7 +149,7 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
                              near: float, far: float, num_coarse: int = 64, num_fine: int = 128,
                              device: str = 'cuda', white_background: bool = True, chunk_size: int = 8192, *,
                              u: Optional[Sequence[Tensor]] = None, u_fine: Optional[Sequence[Tensor]] = None,
-                             return_extras: bool = False):
+                             return_extras: bool = False, coarse_rgb: bool = True):
     """Coarse + fine rendering with inverse-CDF re-sampling.  NOT in the reference (its renderer is
     single pass, rendering.py:156-226); this follows the published NeRF procedure: a stratified
     coarse pass, a per-ray PDF from the interior coarse weights over the mid-points of the coarse
@@ -159,6 +159,10 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
     Returns (rgb_coarse [N,3], rgb_fine [N,3]) -- train on the sum of both MSEs -- plus, with
     return_extras, the fine pass's (weights [N,S], depth [N], acc [N]).  `u[ci]` [num_coarse] and
     `u_fine[ci]` [rays_in_chunk, num_fine] override the random draws of chunk ci.
+
+    coarse_rgb=False (renders without gradients): the coarse image is not needed, so the coarse pass stops at the
+    densities (NeRF in fp32: 16 % of that pass's matrix work is skipped) and rgb_coarse comes back as None; the
+    re-sampling weights, hence the fine image, are bitwise the same.
     """
     rays_o = _f32c(rays_o.to(device))
     rays_d = _f32c(rays_d.to(device))
@@ -175,6 +179,8 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
     wc, wf = coarse.packed_weights(tc_train), fine.packed_weights(tf_train)
     sink_c = grad_sink(coarse, pc) if tc_train else None
     sink_f = grad_sink(fine, pf) if tf_train else None
+    density_only = (not coarse_rgb and not tc_train and not tf_train and coarse.model_id == _hip.MODEL_NERF
+                    and wc.dtype == torch.float32)     # (a bf16 image is uint8: that kernel has no shortened variant)
     out_c, out_f, extras = [], [], []
     for ci, i in enumerate(range(0, rays_o.shape[0], chunk_size)):
         o, d = rays_o[i:i + chunk_size], rays_d[i:i + chunk_size]
@@ -193,6 +199,12 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
             main.wait_stream(side)
             rgb_c.record_stream(main)
             w_c.record_stream(main)
+        elif density_only:
+            # no gradients, no coarse image: densities from the shortened pass, compositing weights only
+            _, dens_c, _ = _hip.mlp_fwd(coarse.model_id, wc, R * num_coarse, rays_o=o, rays_d=d, t=t_c, S=num_coarse,
+                                        near=near, far=far, want_colors=False)
+            rgb_c = None
+            w_c = _hip.composite_fwd(None, dens_c.view(R, num_coarse), deltas_c, bool(white_background))[1]
         else:
             rgb_c, w_c, _, _ = RenderFunction.apply(coarse.model_id, wc, o, d, t_c, deltas_c, float(near), float(far),
                                                     bool(white_background), True, tc_train, sink_c, *pc)
@@ -210,7 +222,8 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
             extras.append(res[1:])
         else:
             out_f.append(res)
-    rgb_c, rgb_f = torch.cat(out_c, dim=0), torch.cat(out_f, dim=0)
+    rgb_c = None if density_only else torch.cat(out_c, dim=0)
+    rgb_f = torch.cat(out_f, dim=0)
     if return_extras:
         return (rgb_c, rgb_f) + tuple(torch.cat([e[k] for e in extras], dim=0) for k in range(3))
     return rgb_c, rgb_f

@@ -952,3 +952,43 @@ def test_fused_resample_equals_the_three_steps(hip, R, Sc, Sf):
     assert torch.equal(g_all, t_all) and torch.equal(g_deltas, deltas)
     idx_ref = torch.searchsorted(cdf.cpu().contiguous(), u.cpu().contiguous(), right=True)
     assert torch.equal(f_idx.cpu().long(), idx_ref)
+
+
+def test_hierarchical_inference_without_coarse_image(hip):
+    """coarse_rgb=False (what eval.py asks for): the coarse pass stops at the densities and the compositor returns weights
+    only -- densities, weights and the fine image are bitwise those of the full pass."""
+    from nerf.models import NeRF, Siren
+    from nerf.rendering import render_nerf_hierarchical
+    coarse, fine = NeRF().to(DEV), NeRF().to(DEV)
+    coarse.load_state_dict(O.closed_form_params(O.nerf_param_shapes()))
+    fine.load_state_dict(O.closed_form_params(O.nerf_param_shapes(), seed=3))
+    o, d = rays(333, 11)
+    o, d = o.to(DEV), d.to(DEV)
+    g = torch.Generator().manual_seed(12)
+    u = [torch.rand(64, generator=g).to(DEV), torch.rand(64, generator=g).to(DEV)]
+    uf = [torch.rand(200, 128, generator=g).to(DEV), torch.rand(133, 128, generator=g).to(DEV)]
+    with torch.no_grad():
+        rc, rf = render_nerf_hierarchical(coarse, fine, o, d, 2.0, 6.0, 64, 128, device=DEV, chunk_size=200, u=u, u_fine=uf)
+        rc2, rf2 = render_nerf_hierarchical(coarse, fine, o, d, 2.0, 6.0, 64, 128, device=DEV, chunk_size=200, u=u, u_fine=uf,
+                                            coarse_rgb=False)
+    assert rc2 is None and rc.shape == (333, 3)
+    assert torch.equal(rf, rf2)
+    # the two entry points on their own
+    t, deltas = hip.stratified_t(2.0, 6.0, 64, u[0])
+    colors, dens, _ = hip.mlp_fwd(coarse.model_id, coarse.packed_weights(False), 333 * 64, rays_o=o, rays_d=d, t=t, S=64, near=2.0, far=6.0)
+    none, dens2, _ = hip.mlp_fwd(coarse.model_id, coarse.packed_weights(False), 333 * 64, rays_o=o, rays_d=d, t=t, S=64, near=2.0,
+                                 far=6.0, want_colors=False)
+    assert none is None and torch.equal(dens, dens2)
+    _, w, _, _ = hip.composite_fwd(colors.view(333, 64, 3), dens.view(333, 64), deltas, True, want_weights=True)
+    rgb_none, w2, _, _ = hip.composite_fwd(None, dens.view(333, 64), deltas, True)
+    assert rgb_none is None and torch.equal(w, w2)
+    # with gradients enabled, or for a Siren pair, the option changes nothing
+    rc3, rf3 = render_nerf_hierarchical(coarse, fine, o[:64], d[:64], 2.0, 6.0, 64, 128, device=DEV, u=[u[0]], u_fine=[uf[0][:64]],
+                                        coarse_rgb=False)
+    assert rc3 is not None and rc3.requires_grad
+    sc, sf = Siren().to(DEV), Siren().to(DEV)
+    with torch.no_grad():
+        rs = render_nerf_hierarchical(sc, sf, o[:64], d[:64], 2.0, 6.0, 64, 128, device=DEV, coarse_rgb=False)
+    assert rs[0] is not None
+    with pytest.raises(ValueError):
+        hip.mlp_fwd(sc.model_id, sc.packed_weights(False), 64, points=o[:64], dirs=d[:64], want_colors=False)
