@@ -34,8 +34,8 @@ import torch.distributed as dist
 
 # algorithmic FLOPs per MLP evaluation (2 * multiply-accumulates)
 FLOPS = {
-    "nerf": {"fwd": 2 * 658944, "dgrad": 2 * 623232, "wgrad": 2 * 658944},
-    "siren": {"fwd": 2 * 561920, "dgrad": 2 * (561920 - 3 * 256 - 27 * 128), "wgrad": 2 * 561920},
+    "nerf": {"fwd": 2 * 658944, "dgrad": 2 * 623232, "wgrad": 2 * 658944, "density": 2 * 556800},
+    "siren": {"fwd": 2 * 561920, "dgrad": 2 * (561920 - 3 * 256 - 27 * 128), "wgrad": 2 * 561920, "density": 2 * 459776},
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (without sparsity)
@@ -310,7 +310,7 @@ def main():
                      ("mlp_bwd_weights", fl["wgrad"], "per-layer weight-gradient GEMMs + one reduction (launch group)")]
         else:
             specs = [("mlp_fwd_infer", fl["fwd"], "fused sample+encode+MLP forward (inference)"),
-                     ("mlp_fwd_infer_density", 2 * 556800, "the same pass stopped after the density row (coarse pass of a "
+                     ("mlp_fwd_infer_density", fl["density"], "the same pass stopped after the density row (coarse pass of a "
                                                            "hierarchical render; no feature layer, rgb layers or head)"),
                      ("mlp_fwd_infer_bf16", fl["fwd"], "bf16 opt-in: register-chain encode+MLP forward (inference)")]
         table = {}
@@ -380,8 +380,7 @@ def main():
             "metric": (f"train rays/sec (fwd+bwd+Adam, {args.coarse}+{args.fine} samples/ray)" if hier else
                        f"train rays/sec (fwd+bwd+Adam, {S} samples/ray single pass)") if args.mode == "train"
                       else (f"inference rays/sec ({S} MLP evaluations/ray"
-                            + (f", the {args.coarse} coarse ones density only)" if hier and args.model == "nerf"
-                               and args.precision != "bf16" else ")")),
+                            + (f", the {args.coarse} coarse ones density only)" if hier and args.precision != "bf16" else ")")),
             "value": world * B * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",

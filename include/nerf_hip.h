@@ -120,7 +120,7 @@ int nerf_mlp_pack(int model, const float* const* params, float* packed, void* st
  *                   M = R*S; sample m belongs to ray m/S and the position is generated and
  *                   normalised in registers as nerf/rendering.py:59-62,82 would (never
  *                   materialised in HBM).
- * Outputs: colors [M,3], density [M].  colors == NULL (NERF_MODEL_NERF, workspace == NULL only): the
+ * Outputs: colors [M,3], density [M].  colors == NULL (workspace == NULL only): the
  * pass stops after the density row and writes densities only -- the coarse pass of a hierarchical
  * render without gradients needs nothing else (no counterpart in the reference, whose renderer is
  * single pass).

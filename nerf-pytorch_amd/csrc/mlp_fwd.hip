@@ -433,8 +433,9 @@ __global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
     DIAG_STAMP(18);
 }
 
-template <bool TRAIN>
+template <bool TRAIN, bool DENSITY_ONLY = false>
 __global__ __launch_bounds__(256, WG_PER_CU) void siren_fwd_kernel(FwdArgs a) {
+    static_assert(!(TRAIN && DENSITY_ONLY), "the density-only pass is an inference variant");
     using namespace lay;
     using namespace lay::siren;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -481,6 +482,12 @@ __global__ __launch_bounds__(256, WG_PER_CU) void siren_fwd_kernel(FwdArgs a) {
     for (int l = 1; l <= 7; ++l)
         hidden_layer<ACT_SIN, TRAIN, H>(act, pk + F_L1 + (size_t)(l - 1) * img(H, H), pk + BIAS + l * H, ncol0, tid,
                                         wsp(WS_H + (size_t)(l - 1) * H, H), wsp(WS_C + (size_t)l * H, H));
+    if constexpr (DENSITY_ONLY) {      // density branch alone: no feature_remap, no rgb layers
+        const float s = row_dot256(act, pk + SIGW, tid) + pk[BIAS_SIG];
+        const size_t m = m0 + tid / TPS;
+        if (tid % TPS == 0 && m < (size_t)a.M) a.density[m] = fmaxf(s, 0.0f) * 10.0f;
+        return;
+    }
     // feature_remap on MFMA, density branch on the VALU (both read h7)
     {
         f32x16 acc[MT][2];
@@ -530,8 +537,8 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
     if (M == 0) return NERF_OK;
     NERF_REQUIRE_PTR(packed);
     NERF_REQUIRE_PTR(density);
-    NERF_REQUIRE(colors != nullptr || (model == NERF_MODEL_NERF && workspace == nullptr),
-                 "nerf_mlp_fwd: colors may be NULL (density only) for the NeRF model without a training workspace only");
+    NERF_REQUIRE(colors != nullptr || workspace == nullptr,
+                 "nerf_mlp_fwd: colors may be NULL (density only) without a training workspace only");
     if (points) {
         NERF_REQUIRE_PTR(dirs);
     } else {
@@ -565,9 +572,12 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
         if (workspace) {
             if ((rc = nerf_set_lds(siren_fwd_kernel<true>, FWD_LDS_BYTES))) return rc;
             siren_fwd_kernel<true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
-        } else {
+        } else if (colors) {
             if ((rc = nerf_set_lds(siren_fwd_kernel<false>, FWD_LDS_BYTES))) return rc;
             siren_fwd_kernel<false><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+        } else {
+            if ((rc = nerf_set_lds(siren_fwd_kernel<false, true>, FWD_LDS_BYTES))) return rc;
+            siren_fwd_kernel<false, true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
         }
     }
     return nerf_check_launch("nerf_mlp_fwd");

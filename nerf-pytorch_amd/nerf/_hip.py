@@ -264,10 +264,10 @@ def mlp_pack(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Ten
 
 def mlp_fwd(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None, rays_o=None, rays_d=None, t=None,
             S: int = 0, near: float = 0.0, far: float = 1.0, train: bool = False, want_colors: bool = True):
-    """want_colors=False (NeRF model, inference only): the pass stops after the density row; colors come back as None."""
+    """want_colors=False (inference only): the pass stops after the density row / branch; colors come back as None."""
     dev = packed.device
-    if not want_colors and (train or model != MODEL_NERF):
-        raise ValueError("the density-only pass is an inference variant of the NeRF model")
+    if not want_colors and train:
+        raise ValueError("the density-only pass is an inference variant")
     colors = torch.empty((M, 3), dtype=torch.float32, device=dev) if want_colors else None
     density = torch.empty((M,), dtype=torch.float32, device=dev)
     ws = None

@@ -161,7 +161,7 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
     `u_fine[ci]` [rays_in_chunk, num_fine] override the random draws of chunk ci.
 
     coarse_rgb=False (renders without gradients): the coarse image is not needed, so the coarse pass stops at the
-    densities (NeRF in fp32: 16 % of that pass's matrix work is skipped) and rgb_coarse comes back as None; the
+    densities (fp32 kernels: 16 % of that pass's matrix work is skipped) and rgb_coarse comes back as None; the
     re-sampling weights, hence the fine image, are bitwise the same.
     """
     rays_o = _f32c(rays_o.to(device))
@@ -179,7 +179,7 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
     wc, wf = coarse.packed_weights(tc_train), fine.packed_weights(tf_train)
     sink_c = grad_sink(coarse, pc) if tc_train else None
     sink_f = grad_sink(fine, pf) if tf_train else None
-    density_only = (not coarse_rgb and not tc_train and not tf_train and coarse.model_id == _hip.MODEL_NERF
+    density_only = (not coarse_rgb and not tc_train and not tf_train
                     and wc.dtype == torch.float32)     # (a bf16 image is uint8: that kernel has no shortened variant)
     out_c, out_f, extras = [], [], []
     for ci, i in enumerate(range(0, rays_o.shape[0], chunk_size)):

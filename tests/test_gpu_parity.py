@@ -986,9 +986,13 @@ def test_hierarchical_inference_without_coarse_image(hip):
     rc3, rf3 = render_nerf_hierarchical(coarse, fine, o[:64], d[:64], 2.0, 6.0, 64, 128, device=DEV, u=[u[0]], u_fine=[uf[0][:64]],
                                         coarse_rgb=False)
     assert rc3 is not None and rc3.requires_grad
+    # Siren: the density branch alone
     sc, sf = Siren().to(DEV), Siren().to(DEV)
+    sc.load_state_dict(O.closed_form_params(O.siren_param_shapes(), gains=O.SIREN_GAINS))
+    sf.load_state_dict(O.closed_form_params(O.siren_param_shapes(), gains=O.SIREN_GAINS, seed=5))
     with torch.no_grad():
-        rs = render_nerf_hierarchical(sc, sf, o[:64], d[:64], 2.0, 6.0, 64, 128, device=DEV, coarse_rgb=False)
-    assert rs[0] is not None
+        a = render_nerf_hierarchical(sc, sf, o, d, 2.0, 6.0, 64, 128, device=DEV, chunk_size=200, u=u, u_fine=uf)
+        b = render_nerf_hierarchical(sc, sf, o, d, 2.0, 6.0, 64, 128, device=DEV, chunk_size=200, u=u, u_fine=uf, coarse_rgb=False)
+    assert b[0] is None and torch.equal(a[1], b[1])
     with pytest.raises(ValueError):
-        hip.mlp_fwd(sc.model_id, sc.packed_weights(False), 64, points=o[:64], dirs=d[:64], want_colors=False)
+        hip.mlp_fwd(sc.model_id, sc.packed_weights(True), 64, points=o[:64], dirs=d[:64], want_colors=False, train=True)
