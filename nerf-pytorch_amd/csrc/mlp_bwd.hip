@@ -553,7 +553,7 @@ void thin(Ctx& c, const float* P, int ldp, int AW, const float* Q, int NB, float
         return;
     }
     int64_t G = (int64_t)c.Mp / 64;
-    if (G > 512) G = 512;
+    if (G > lay::THIN_MAX) G = lay::THIN_MAX;
     float* tslab = c.take((int)G, NB * AW);
     float* pslab = db_wide ? c.take((int)G, AW) : nullptr;
     float* qslab = db_thin ? c.take((int)G, 4) : nullptr;

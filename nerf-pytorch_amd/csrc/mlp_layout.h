@@ -117,12 +117,13 @@ constexpr size_t BW_PER_SAMPLE = BW_DSIG + 1;
 }  // namespace siren
 
 // Weight-gradient partial slabs.  Every per-layer launch owns a region [G][outputs] of the slab area (G <=
-// WG_MAX workgroups for the MFMA launches, <= 512 for the thin VALU products), so that ONE reduction launch
+// WG_MAX workgroups for the MFMA launches, <= THIN_MAX for the thin VALU products), so that ONE reduction launch
 // can add all of them at the end.  Per G the MFMA launches of the larger network (NeRF) write
 // 2*(256*64) + 9*(256*256) + 128*256 + 128*32 weight partials and 10*256 + 128 + 256 + 4 bias / rank-1
 // partials = 662,404 floats; the thin products at most 3*256 + 256 + 4 floats.
 constexpr int WG_MAX = 256;
-constexpr size_t SLAB_FLOATS = (size_t)WG_MAX * 664000 + (size_t)512 * 2048;
+constexpr int THIN_MAX = 1024;   // 512 left the thin products at 3.5 TB/s, 2048+ only lengthens the reduction
+constexpr size_t SLAB_FLOATS = (size_t)WG_MAX * 664000 + (size_t)THIN_MAX * 1100;
 
 inline size_t padded_samples(long long M) { return (size_t)((M + TILE - 1) / TILE) * TILE; }
 
