@@ -171,8 +171,9 @@ def main():
                          "'64+128 samples/ray'); single: the reference's own single pass of --samples (config_lego.txt:15)")
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=128)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="bf16: the opt-in inference mode (--mode infer, nerf only); never the default metric")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
+                    help="bf16 / bf16x3: the opt-in inference modes on the bf16 matrix pipe (--mode infer, nerf only; bf16x3 = "
+                         "three-term split at fp32 accuracy); never the default metric")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the multi-rank code path on a box with a single GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -215,11 +216,11 @@ def main():
     Model = NeRF if args.model == "nerf" else Siren
     models = [Model().to(dev) for _ in range(2 if hier else 1)]   # [coarse, fine] or [single]
     model = models[0]
-    if args.precision == "bf16":
+    if args.precision != "fp32":
         if args.mode != "infer":
-            raise SystemExit("--precision bf16 is an inference-only mode: add --mode infer")
+            raise SystemExit(f"--precision {args.precision} is an inference-only mode: add --mode infer")
         for m in models:
-            m.set_inference_precision("bf16")
+            m.set_inference_precision(args.precision)
     flat = parallel.FlatParameters(torch.nn.ModuleList(models))   # one bucket, one all-reduce, one Adam launch
     flat.broadcast_parameters(0)
     opt = parallel.FusedAdam(flat, lr=5e-4)
@@ -312,7 +313,9 @@ def main():
             specs = [("mlp_fwd_infer", fl["fwd"], "fused sample+encode+MLP forward (inference)"),
                      ("mlp_fwd_infer_density", fl["density"], "the same pass stopped after the density row (coarse pass of a "
                                                            "hierarchical render; no feature layer, rgb layers or head)"),
-                     ("mlp_fwd_infer_bf16", fl["fwd"], "bf16 opt-in: register-chain encode+MLP forward (inference)")]
+                     ("mlp_fwd_infer_bf16", fl["fwd"], "bf16 opt-in: register-chain encode+MLP forward (inference)"),
+                     ("mlp_fwd_infer_bf16x3", 6 * fl["fwd"], "bf16x3 opt-in: the same chain with every fp32 operand as three bf16 terms; "
+                                                             "matrix-pipe flops = 6 term products per product of the fp32 algorithm")]
         table = {}
         for base, flop_per_sample, desc in specs:
             for name in (base, base + "@side"):
@@ -366,7 +369,7 @@ def main():
             ach = m["flop"] / m["ms"] / 1e9
             samples_per_launch = m["flop"] / m["n"] / m["per_sample"]
             tb, tb_files = pmc_traffic_per_sample(args.model, dom)
-            peak = PEAK_BF16_MFMA_TFLOPS if dom.endswith("bf16") else PEAK_F32_MFMA_TFLOPS
+            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom else PEAK_F32_MFMA_TFLOPS
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                     "frac": ach / peak, "traffic": tb * samples_per_launch if tb else None,
                     "traffic_unit": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) per sample of the rocprofv3 --pmc "
@@ -380,22 +383,23 @@ def main():
             "metric": (f"train rays/sec (fwd+bwd+Adam, {args.coarse}+{args.fine} samples/ray)" if hier else
                        f"train rays/sec (fwd+bwd+Adam, {S} samples/ray single pass)") if args.mode == "train"
                       else (f"inference rays/sec ({S} MLP evaluations/ray"
-                            + (f", the {args.coarse} coarse ones density only)" if hier and args.precision != "bf16" else ")")),
+                            + (f", the {args.coarse} coarse ones density only)" if hier and args.precision == "fp32" else ")")),
             "value": world * B * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3 (three bf16 terms per fp32 operand, fp32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"lego-shaped synthetic {args.res}x{args.res} scene, {B} rays/GPU/step, "
                                    + (f"{args.coarse} coarse + ({args.coarse}+{args.fine}) fine = {S} MLP evaluations/ray, "
                                       f"coarse+fine {args.model} MLPs" if hier else
                                       f"{S} samples/ray single pass, one {args.model} MLP")
-                                   + (" (bf16 MFMA, fp32 accumulate)" if args.precision == "bf16" else " (fp32 MFMA)") + f", {args.mode}", "network": args.model, "sampling": args.sampling,
+                                   + {"fp32": " (fp32 MFMA)", "bf16": " (bf16 MFMA, fp32 accumulate)",
+                                      "bf16x3": " (fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate)"}[args.precision] + f", {args.mode}", "network": args.model, "sampling": args.sampling,
                        "rays_per_gpu": B, "rays_per_step": B * world, "mlp_evals_per_ray": S,
                        "parallelism": f"dp{world} ray-sharded, flat-bucket RCCL all-reduce" if world > 1 else "single GPU"},
             "roofline": roof,
             "kernels": kernels,
             "kernels_serialized": kernel_table(tm_serial, 2) if tm_serial else None,
             "step_mfma_frac": (total_flop / (ms_step * 1e-3) / 1e12)
-                              / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
+                              / (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS),
             "final_value": final,
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":

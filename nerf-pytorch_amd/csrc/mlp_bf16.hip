@@ -19,6 +19,16 @@
 // publishes chunk c and releases the buffer of chunk c-1 for chunk c+3.  The image is stored in
 // consumption order, one 1 KiB unit per MFMA: unit[lane][8 bf16] is read back with one
 // conflict-free ds_read_b128 per lane.
+//
+// Three-term variant (PLANES = 3, "bf16x3").  Every fp32 operand is written as the sum of three bf16 terms,
+// x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (the subtractions are exact), and a
+// product of two operands is formed from the six term products that reach fp32 precision:
+//     w*x ~= w0*x0 + w0*x1 + w0*x2 + w1*x0 + w1*x1 + w2*x0      (what is dropped is below 2^-24 of |w*x|)
+// -- six bf16 MFMAs (32 cycles each for 16 k) in place of eight fp32 ones (64 cycles each for 2 k).  Every term product
+// is exact in the fp32 accumulator, so the result carries the rounding of an fp32 accumulation and nothing else: this
+// mode holds the fp32 parity bar, unlike the one-term mode.  The weight image stores the three terms of an A fragment
+// as three consecutive units; a wave keeps three B fragments per k-step (192 registers of activations), which is why a
+// workgroup is 4 waves of 512 registers here instead of 8 waves of 256; encodings use the fp32 path's sincos.
 #include "mlp_device.h"
 
 #include <utility>
@@ -35,8 +45,6 @@ constexpr int UNIT_BYTES = 1024;     // one A fragment for a whole wave
 constexpr int CHUNK_UNITS = 32;
 constexpr int CHUNK_BYTES = CHUNK_UNITS * UNIT_BYTES;
 constexpr int NBUF = 4;
-constexpr int WG_THREADS = 512;
-constexpr int WG_SAMPLES = 256;
 
 // ---- layer table -------------------------------------------------------------------------
 enum Enc { ENC_NONE = 0, ENC_PE = 1, ENC_DE = 2 };
@@ -58,24 +66,42 @@ constexpr LayerInfo LAYERS[NL] = {
 };
 constexpr int enc_ks(int enc) { return enc == ENC_PE ? 4 : enc == ENC_DE ? 2 : 0; }
 constexpr int layer_ks(int l) { return LAYERS[l].nks_acc + enc_ks(LAYERS[l].enc); }
-constexpr int layer_units(int l) { return LAYERS[l].n_ot * layer_ks(l); }
-constexpr int layer_chunks(int l) { return (layer_units(l) + CHUNK_UNITS - 1) / CHUNK_UNITS; }
-constexpr int chunk0(int l) {
-    int c = 0;
-    for (int i = 0; i < l; ++i) c += layer_chunks(i);
-    return c;
-}
 constexpr int bias_tile0(int l) {
     int t = 0;
     for (int i = 0; i < l; ++i) t += LAYERS[i].n_ot;
     return t;
 }
-constexpr int NCHUNK = chunk0(NL);
 constexpr int NBIAS_TILES = bias_tile0(NL);
-constexpr size_t IMG_BYTES = (size_t)NCHUNK * CHUNK_BYTES;
 constexpr size_t BIAS_FLOATS = (size_t)NBIAS_TILES * 32;
-constexpr size_t PACKED_BYTES = IMG_BYTES + BIAS_FLOATS * 4;
-static_assert(NCHUNK == 43 && NBIAS_TILES == 86, "bf16 image layout");
+
+// Geometry of the P-term kernel: P units (one per term) for every A fragment, every layer starts a new chunk.
+template <int P>
+struct Geo {
+    static constexpr int WG_THREADS = P == 1 ? 512 : 256;
+    static constexpr int WG_SAMPLES = WG_THREADS / 2;                        // a wave owns 32 samples
+    static constexpr int PER_CHUNK = CHUNK_BYTES / (16 * WG_THREADS);        // LDS-DMA instructions per thread and chunk
+    static constexpr int layer_units(int l) { return P * LAYERS[l].n_ot * layer_ks(l); }
+    static constexpr int layer_chunks(int l) { return (layer_units(l) + CHUNK_UNITS - 1) / CHUNK_UNITS; }
+    static constexpr int chunk0(int l) {
+        int c = 0;
+        for (int i = 0; i < l; ++i) c += layer_chunks(i);
+        return c;
+    }
+    static constexpr int NCHUNK = chunk0(NL);
+    static constexpr size_t IMG_BYTES = (size_t)NCHUNK * CHUNK_BYTES;
+    static constexpr size_t PACKED_BYTES = IMG_BYTES + BIAS_FLOATS * 4;
+};
+static_assert(Geo<1>::NCHUNK == 43 && Geo<3>::NCHUNK == 124 && NBIAS_TILES == 86, "bf16 image layout");
+
+// term `plane` of the three-term bf16 expansion of x (term 0 alone is the plain bf16 rounding)
+__host__ __device__ inline __bf16 bf16_term(float x, int plane) {
+    __bf16 t = (__bf16)x;
+    for (int i = 0; i < plane; ++i) {
+        x -= (float)t;      // exact: the difference of a float and its bf16 rounding fits a float
+        t = (__bf16)x;
+    }
+    return t;
+}
 
 // input column of weight element (k-step ks, lane half h, fragment element j) of layer L, or -1
 __host__ __device__ inline int k_column(const LayerInfo& L, int ks, int h, int j) {
@@ -103,7 +129,10 @@ struct PackBf16Args {
     int bias_tile0[NL + 1];
 };
 
+template <int P>
 __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBf16Args a) {
+    constexpr int NCHUNK = Geo<P>::NCHUNK;
+    constexpr size_t IMG_BYTES = Geo<P>::IMG_BYTES;
     const int p = blockIdx.x * 256 + threadIdx.x;  // one 16-byte piece: unit, lane
     if (p < NCHUNK * CHUNK_UNITS * 64) {
         const int chunk = p / (CHUNK_UNITS * 64), unit = (p / 64) % CHUNK_UNITS, lane = p & 63;
@@ -111,7 +140,8 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBf16Args a) {
         while (chunk >= a.chunk0[l + 1]) ++l;
         const LayerInfo L = a.layers[l];
         const int nks = L.nks_acc + (L.enc == ENC_PE ? 4 : L.enc == ENC_DE ? 2 : 0);
-        const int u = (chunk - a.chunk0[l]) * CHUNK_UNITS + unit;
+        const int up = (chunk - a.chunk0[l]) * CHUNK_UNITS + unit;
+        const int plane = up % P, u = up / P;       // the P terms of a fragment are consecutive units
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.0f;
@@ -123,7 +153,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBf16Args a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int col = k_column(L, ks, h, j);
-                    if (col >= 0) v[j] = (__bf16)w[col];
+                    if (col >= 0) v[j] = bf16_term(w[col], plane);
                 }
             }
         }
@@ -176,44 +206,43 @@ struct Ring {
     const unsigned char* img;
     unsigned char* lds;
     int next;        // chunk the next begin_chunk() hands out
-    unsigned voff;   // this thread's byte offset inside a 8 KiB slice of a chunk (16 * tid)
+    unsigned voff;   // this thread's byte offset inside a slice of a chunk (16 * tid)
     int wave;
+    int nchunk, img_bytes, per_chunk, wg_threads;   // Geo<P> of the kernel (compile-time constants after inlining)
 };
-constexpr int PER_CHUNK = CHUNK_BYTES / (16 * WG_THREADS);   // global_load_lds instructions per thread and chunk
 
-__device__ __forceinline__ void ring_issue(const Ring& r, int chunk) {
-    if (chunk < NCHUNK) {
+// piece i (16 bytes per thread) of a chunk: global memory -> LDS without staging registers
+__device__ __forceinline__ void ring_issue_piece(const Ring& r, int chunk, int i) {
+    if (chunk < r.nchunk) {
         // buffer form of the LDS-DMA: image base and size in a scalar resource, the chunk and the slice in the scalar
         // offset, this thread's 16 * tid in the one vector offset that never changes -- no vector address arithmetic
         const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(r.img), 0, (int)IMG_BYTES, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(r.img), 0, r.img_bytes, 0x00020000);
         unsigned char* dst = r.lds + (chunk & (NBUF - 1)) * CHUNK_BYTES + 16 * 64 * r.wave;
-#pragma unroll
-        for (int i = 0; i < PER_CHUNK; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + i * 16 * WG_THREADS), 16,
-                                                     (int)r.voff, chunk * CHUNK_BYTES + i * 16 * WG_THREADS, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + i * 16 * r.wg_threads), 16,
+                                                 (int)r.voff, chunk * CHUNK_BYTES + i * 16 * r.wg_threads, 0, 0);
     }
+}
+__device__ __forceinline__ void ring_issue(const Ring& r, int chunk) {
+#pragma unroll
+    for (int i = 0; i < r.per_chunk; ++i) ring_issue_piece(r, chunk, i);
 }
 
 // Ring protocol.  While the waves read chunk c (already published), chunk c+1 is published a few
 // units into c: every wave waits for its own pieces of c+1 (counted vmcnt: c+2 may stay in flight),
 // all waves meet at one barrier, and the buffer of chunk c-1 -- which no wave can still be reading,
-// each having consumed at least one unit of c -- is refilled with chunk c+3.  The fragment reads of
+// each having consumed at least one unit of c -- is refilled with chunk c+3, one piece per following unit: an
+// LDS-DMA instruction holds the issuing wave for some tens of cycles, which one MFMA covers and eight in a row do
+// not (the three-term kernel has no second wave on the SIMD to fill the gap).  The fragment reads of
 // chunk c that are in flight at the barrier are untouched by it, so the MFMA stream never drains.
-__device__ __forceinline__ const unsigned char* ring_begin_chunk(Ring& r) {
-    const unsigned char* buf = r.lds + (r.next & (NBUF - 1)) * CHUNK_BYTES;
-    ++r.next;
-    return buf;
-}
 // REM = chunks of the whole stream that follow the one being read (2 = two or more)
-template <int REM>
+template <int P, int REM>
 __device__ __forceinline__ void ring_publish_next(Ring& r) {
     if constexpr (REM >= 1) {
-        if constexpr (REM >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
+        if constexpr (REM >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Geo<P>::PER_CHUNK) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        ring_issue(r, r.next + 2);   // r.next is the chunk just published
     }
 }
 
@@ -235,10 +264,6 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[9], const float* bias_ld
     }
 }
 
-// acc[ot] += W tile (ot, ks) * B(ks) for all ks, consuming the layer's units in image order; k-steps
-// below NKS_A take their B fragment from XA, the rest from XE (an encoding).  A fragments are read
-// from LDS PF units ahead of the MFMA that uses them.
-// TAIL = chunks that follow this layer's last chunk in the whole stream (2 = two or more).
 template <int... I, typename F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -250,13 +275,20 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-template <int NOT, int NKS_A, int NKS_E, int TAIL>
-__device__ __forceinline__ void mma_layer16(Ring& r, int lane, f32x16 (&acc)[9], const bf16x8 (&XA)[16],
-                                            const bf16x8 (&XE)[4]) {
-    constexpr int NKS = NKS_A + NKS_E, UNITS = NOT * NKS, CHUNKS = (UNITS + CHUNK_UNITS - 1) / CHUNK_UNITS;
-    constexpr int PF = 4;            // fragment reads in flight
+// acc[ot] += W tile (ot, ks) * B(ks) for all ks, consuming the layer's units in image order; k-steps
+// below NKS_A take their B fragment from XA, the rest from XE (an encoding).  A fragments are read
+// from LDS PF units ahead of the MFMAs that use them.  With P = 3 terms, unit 3g+p is term p of fragment g and
+// meets the terms 0..2-p of the B fragment (3 + 2 + 1 MFMAs per fragment, consecutive ones on one accumulator
+// run at full rate).
+// TAIL = chunks that follow this layer's last chunk in the whole stream (2 = two or more).
+template <int P, int NOT, int NKS_A, int NKS_E, int TAIL>
+__device__ __forceinline__ void mma_layer16(Ring& r, int lane, f32x16 (&acc)[9], const bf16x8 (&XA)[P][16],
+                                            const bf16x8 (&XE)[P][4]) {
+    constexpr int NKS = NKS_A + NKS_E, UNITS = P * NOT * NKS, CHUNKS = (UNITS + CHUNK_UNITS - 1) / CHUNK_UNITS;
+    constexpr int PF = 4;            // fragment reads in flight (8 measure the same in both kernels)
     constexpr int PUBLISH_AT = PF;   // unit of a chunk at whose fetch the next chunk is published
-    static_assert(UNITS >= PF && (UNITS % CHUNK_UNITS == 0 || UNITS % CHUNK_UNITS > PUBLISH_AT), "chunk too short");
+    constexpr int PER_CHUNK = Geo<P>::PER_CHUNK;
+    static_assert(UNITS >= PF && (UNITS % CHUNK_UNITS == 0 || UNITS % CHUNK_UNITS >= PUBLISH_AT + PER_CHUNK), "chunk too short");
     const unsigned char* buf = nullptr;
     bf16x8 a[PF];
     auto fetch = [&](auto U) {
@@ -269,20 +301,23 @@ __device__ __forceinline__ void mma_layer16(Ring& r, int lane, f32x16 (&acc)[9],
             ++r.next;
             buf = r.lds + off;
         }
-        if constexpr (u % CHUNK_UNITS == PUBLISH_AT) {
-            constexpr int rem = (CHUNKS - 1 - u / CHUNK_UNITS) + TAIL;
-            ring_publish_next<(rem >= 2 ? 2 : rem)>(r);
-        }
+        constexpr int rem = (CHUNKS - 1 - u / CHUNK_UNITS) + TAIL;
+        if constexpr (u % CHUNK_UNITS == PUBLISH_AT) ring_publish_next<P, (rem >= 2 ? 2 : rem)>(r);
+        if constexpr (rem >= 1 && u % CHUNK_UNITS >= PUBLISH_AT && u % CHUNK_UNITS < PUBLISH_AT + PER_CHUNK)
+            ring_issue_piece(r, r.next + 2, u % CHUNK_UNITS - PUBLISH_AT);   // r.next is the chunk just published
         a[u % PF] = *reinterpret_cast<const bf16x8*>(buf + (u % CHUNK_UNITS) * UNIT_BYTES);
     };
     static_for<PF>(fetch);
     static_for<UNITS>([&](auto U) {
-        constexpr int u = decltype(U)::value, ks = u / NOT, ot = u % NOT;
-        bf16x8 b;
-        if constexpr (ks < NKS_A) b = XA[ks];
-        else b = XE[ks - NKS_A];
+        constexpr int u = decltype(U)::value, p = u % P, ks = (u / P) / NOT, ot = (u / P) % NOT;
         __builtin_amdgcn_sched_barrier(0);
-        acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % PF], b, acc[ot], 0, 0, 0);
+        static_for<P - p>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            bf16x8 b;
+            if constexpr (ks < NKS_A) b = XA[q][ks];
+            else b = XE[q][ks - NKS_A];
+            acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % PF], b, acc[ot], 0, 0, 0);
+        });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (u + PF < UNITS) fetch(std::integral_constant<int, u + PF>{});
     });
@@ -292,46 +327,83 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
+// the P bf16 terms of a pair of floats, each as a packed pair
+template <int P>
+__device__ __forceinline__ void split2(float v0, float v1, unsigned (&w)[P]) {
+    w[0] = pack2(v0, v1);
+#pragma unroll
+    for (int p = 1; p < P; ++p) {
+#pragma clang fp contract(off)
+        v0 -= __builtin_bit_cast(float, w[p - 1] << 16);           // exact
+        v1 -= __builtin_bit_cast(float, w[p - 1] & 0xffff0000u);
+        w[p] = pack2(v0, v1);
+    }
+}
+
 // accumulator tiles -> B fragments of the next layer (two k-steps per 32-feature tile)
-template <int NFT, bool RELU>
-__device__ __forceinline__ void to_frags(const f32x16 (&acc)[9], bf16x8* X) {
+template <int P, int NFT, bool RELU>
+__device__ __forceinline__ void to_frags(const f32x16 (&acc)[9], bf16x8 (&X)[P][16]) {
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            u32x4 w;
+            u32x4 w[P];
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) {
-                // ReLU on the packed pair: as 16-bit integers, negative bf16 values are negative
-                const unsigned pk = pack2(acc[ft][8 * s + 2 * jp], acc[ft][8 * s + 2 * jp + 1]);
-                w[jp] = RELU ? __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), s16x2{0, 0}))
-                             : pk;
+                float v0 = acc[ft][8 * s + 2 * jp], v1 = acc[ft][8 * s + 2 * jp + 1];
+                if constexpr (P == 1) {
+                    // ReLU on the packed pair: as 16-bit integers, negative bf16 values are negative
+                    const unsigned pk = pack2(v0, v1);
+                    w[0][jp] = RELU ? __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), s16x2{0, 0}))
+                                    : pk;
+                } else {
+                    if (RELU) {   // (fmaxf puts a canonicalising v_max v, v, v in front of the v_max)
+                        asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
+                        asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+                    }
+                    unsigned t[P];
+                    split2<P>(v0, v1, t);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) w[p][jp] = t[p];
+                }
             }
-            X[2 * ft + s] = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+            for (int p = 0; p < P; ++p) X[p][2 * ft + s] = __builtin_bit_cast(bf16x8, w[p]);
         }
 }
 
-template <int N>
-__device__ __forceinline__ void vals_to_frags(const float (&v)[N], bf16x8* X) {
+template <int P, int N>
+__device__ __forceinline__ void vals_to_frags(const float (&v)[N], bf16x8 (&X)[P][4]) {
 #pragma unroll
     for (int ks = 0; ks < N / 8; ++ks) {
-        u32x4 w;
+        u32x4 w[P];
 #pragma unroll
-        for (int jp = 0; jp < 4; ++jp) w[jp] = pack2(v[8 * ks + 2 * jp], v[8 * ks + 2 * jp + 1]);
-        X[ks] = __builtin_bit_cast(bf16x8, w);
+        for (int jp = 0; jp < 4; ++jp) {
+            unsigned t[P];
+            split2<P>(v[8 * ks + 2 * jp], v[8 * ks + 2 * jp + 1], t);
+#pragma unroll
+            for (int p = 0; p < P; ++p) w[p][jp] = t[p];
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) X[p][ks] = __builtin_bit_cast(bf16x8, w[p]);
     }
 }
 
-// sin/cos of s0*2^f*x for f = 0..NF-1: one accurate sincos at the base frequency, then angle
-// doubling (sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a).  The absolute error doubles per step:
-// about 1e-6 after four steps, three orders below half a bf16 ulp of the values it feeds.
-template <int NF>
+// sin/cos of s0*2^f*x for f = 0..NF-1.  One term: one accurate sincos at the base frequency, then angle
+// doubling (sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a); the absolute error doubles per step:
+// about 1e-6 after four steps, three orders below half a bf16 ulp of the values it feeds.  Three terms: the
+// fp32 path's sincos of the exactly scaled argument at every frequency (nerf/encoding.py:14-18).
+template <int P, int NF>
 __device__ __forceinline__ void sincos_octaves(float base_arg, float (&sn)[NF], float (&cs)[NF]) {
     nerf_sincosf(base_arg, &sn[0], &cs[0]);
 #pragma unroll
     for (int f = 1; f < NF; ++f) {
-        sn[f] = 2.0f * sn[f - 1] * cs[f - 1];
-        cs[f] = fmaf(-2.0f * sn[f - 1], sn[f - 1], 1.0f);
+        if constexpr (P == 1) {
+            sn[f] = 2.0f * sn[f - 1] * cs[f - 1];
+            cs[f] = fmaf(-2.0f * sn[f - 1], sn[f - 1], 1.0f);
+        } else {
+            nerf_sincosf(mul_rn((float)(1 << f), base_arg), &sn[f], &cs[f]);
+        }
     }
 }
 
@@ -340,7 +412,10 @@ __device__ __forceinline__ float norm_coord16(float p, float nearf, float spanf)
     return sub_rn(div_rn(mul_rn(2.0f, sub_rn(p, nearf)), spanf), 1.0f);
 }
 
-__global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a) {
+template <int P>
+__global__ __launch_bounds__(Geo<P>::WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a) {
+    using G = Geo<P>;
+    constexpr int WG_THREADS = G::WG_THREADS, WG_SAMPLES = G::WG_SAMPLES, PER_CHUNK = G::PER_CHUNK;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     float* bias_lds = reinterpret_cast<float*>(smem + NBUF * CHUNK_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -350,7 +425,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
     DIAG_STAMP(0);
     // Ordinary loads first (inputs, bias image -> LDS): once LDS-DMA loads are in flight the compiler
     // waits for ALL of them at the first use of an ordinary load's result.
-    const float* bias_g = reinterpret_cast<const float*>(a.img + IMG_BYTES);
+    const float* bias_g = reinterpret_cast<const float*>(a.img + G::IMG_BYTES);
     for (int i = tid; i < (int)BIAS_FLOATS; i += WG_THREADS) bias_lds[i] = bias_g[i];
 
     // both lane halves load the sample of lane & 31
@@ -377,7 +452,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing ordinary is outstanding from here on
     __builtin_amdgcn_sched_barrier(0);
-    Ring ring{a.img, smem, 0, 16u * (unsigned)tid, wave};
+    Ring ring{a.img, smem, 0, 16u * (unsigned)tid, wave, G::NCHUNK, (int)G::IMG_BYTES, PER_CHUNK, WG_THREADS};
     ring_issue(ring, 0);   // these land while the encodings below are computed
     ring_issue(ring, 1);
     ring_issue(ring, 2);
@@ -385,14 +460,14 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
 
     // encodings in the slot order k_column() gives the weight image: half h owns frequencies
     // 5h..5h+4 of the position and 2h..2h+1 of the direction, the raw coordinates fill the tail
-    bf16x8 PE[4];
+    bf16x8 PE[P][4];
     {
         float v[32];
         const float s0 = h ? 32.0f : 1.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float sn[5], cs[5];
-            sincos_octaves<5>(mul_rn(s0, x[c]), sn, cs);
+            sincos_octaves<P, 5>(mul_rn(s0, x[c]), sn, cs);
 #pragma unroll
             for (int f = 0; f < 5; ++f) {
                 v[6 * f + c] = sn[f];
@@ -401,7 +476,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
         }
         v[30] = h ? x[2] : x[0];
         v[31] = h ? 0.0f : x[1];
-        vals_to_frags<32>(v, PE);
+        vals_to_frags<P, 32>(v, PE);
     }
     // publish chunk 0 and the bias image: own pieces of chunk 0 landed (chunks 1, 2 stay in flight),
     // own LDS writes done, then the barrier
@@ -411,47 +486,47 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
     DIAG_STAMP(1);
 
     f32x16 acc[9];
-    bf16x8 X[16];
+    bf16x8 X[P][16];
 
     init_bias<8>(acc, bias_lds, bias_tile0(0), h);
-    mma_layer16<8, 0, 4, 2>(ring, lane, acc, X, PE);
-    to_frags<8, true>(acc, X);
+    mma_layer16<P, 8, 0, 4, 2>(ring, lane, acc, X, PE);
+    to_frags<P, 8, true>(acc, X);
     DIAG_STAMP(2);
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
         init_bias<8>(acc, bias_lds, 8 * l, h);
         DIAG_STAMP(10 + 3 * (l - 1));
-        mma_layer16<8, 16, 0, 2>(ring, lane, acc, X, PE);
+        mma_layer16<P, 8, 16, 0, 2>(ring, lane, acc, X, PE);
         DIAG_STAMP(11 + 3 * (l - 1));
-        to_frags<8, true>(acc, X);
+        to_frags<P, 8, true>(acc, X);
         DIAG_STAMP(12 + 3 * (l - 1));
     }
     DIAG_STAMP(3);
     // skip layer: [features | position encoding]
     init_bias<8>(acc, bias_lds, bias_tile0(5), h);
-    mma_layer16<8, 16, 4, 2>(ring, lane, acc, X, PE);
-    to_frags<8, true>(acc, X);
+    mma_layer16<P, 8, 16, 4, 2>(ring, lane, acc, X, PE);
+    to_frags<P, 8, true>(acc, X);
 #pragma unroll 1
     for (int l = 6; l <= 8; ++l) {
         init_bias<8>(acc, bias_lds, 8 * l, h);
-        mma_layer16<8, 16, 0, 2>(ring, lane, acc, X, PE);
-        to_frags<8, true>(acc, X);
+        mma_layer16<P, 8, 16, 0, 2>(ring, lane, acc, X, PE);
+        to_frags<P, 8, true>(acc, X);
     }
     // block2.8: 256 feature rows (no activation) + the density row (first row of the ninth tile)
     init_bias<9>(acc, bias_lds, bias_tile0(9), h);
-    mma_layer16<9, 16, 0, 2>(ring, lane, acc, X, PE);
+    mma_layer16<P, 9, 16, 0, 2>(ring, lane, acc, X, PE);
     const float dens = fmaxf(acc[8][0], 0.0f);
-    to_frags<8, false>(acc, X);
+    to_frags<P, 8, false>(acc, X);
     // rgb head: [features | direction encoding] -> 128, ReLU.  The direction encoding is only
     // computed now: its registers would otherwise be held through the whole trunk.
-    bf16x8 DE[4];
+    bf16x8 DE[P][4];
     {
         float v[16];
         const float s0 = h ? 4.0f : 1.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float sn[2], cs[2];
-            sincos_octaves<2>(mul_rn(s0, d[c]), sn, cs);
+            sincos_octaves<P, 2>(mul_rn(s0, d[c]), sn, cs);
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 v[6 * f + c] = sn[f];
@@ -461,13 +536,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[12 + c] = h ? 0.0f : d[c];
         v[15] = 0.0f;
-        vals_to_frags<16>(v, DE);
+        vals_to_frags<P, 16>(v, DE);
     }
     init_bias<4>(acc, bias_lds, bias_tile0(10), h);
-    mma_layer16<4, 16, 2, 1>(ring, lane, acc, X, DE);
-    to_frags<4, true>(acc, X);
+    mma_layer16<P, 4, 16, 2, 1>(ring, lane, acc, X, DE);
+    to_frags<P, 4, true>(acc, X);
     init_bias<1>(acc, bias_lds, bias_tile0(11), h);
-    mma_layer16<1, 8, 0, 0>(ring, lane, acc, X, DE);
+    mma_layer16<P, 1, 8, 0, 0>(ring, lane, acc, X, DE);
 
     DIAG_STAMP(4);
     if (valid && h == 0) {  // rows 0..2 of the last tile and the density row sit in lane half 0
@@ -478,6 +553,25 @@ __global__ __launch_bounds__(WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a
     DIAG_STAMP(5);
 }
 
+template <int P>
+int pack_image(const float* const* params, void* packed, void* stream, const char* who) {
+    using G = Geo<P>;
+    PackBf16Args a;
+    for (int i = 0; i < NERF_NUM_PARAM_TENSORS; ++i) {
+        if (!params[i]) return nerf_fail(NERF_E_NULL, "%s: params[%d] is NULL", who, i);
+        a.src[i] = params[i];
+    }
+    a.dst = static_cast<unsigned char*>(packed);
+    for (int l = 0; l < NL; ++l) a.layers[l] = LAYERS[l];
+    for (int l = 0; l <= NL; ++l) {
+        a.chunk0[l] = G::chunk0(l);
+        a.bias_tile0[l] = bias_tile0(l);
+    }
+    const int pieces = G::NCHUNK * CHUNK_UNITS * 64;
+    pack_bf16_kernel<P><<<(pieces + 255) / 256, 256, 0, (hipStream_t)stream>>>(a);
+    return nerf_check_launch(who);
+}
+
 }  // namespace
 
 #ifdef NERF_DIAG
@@ -485,55 +579,61 @@ static unsigned long long* g_bf16_dbg = nullptr;
 extern "C" void nerf_diag_bf16_stamps(unsigned long long* device_buffer) { g_bf16_dbg = device_buffer; }
 #endif
 
-extern "C" size_t nerf_mlp_packed_bf16_bytes(int model) { return model == NERF_MODEL_NERF ? PACKED_BYTES : 0; }
+extern "C" size_t nerf_mlp_packed_bf16_bytes(int model) { return model == NERF_MODEL_NERF ? Geo<1>::PACKED_BYTES : 0; }
+extern "C" size_t nerf_mlp_packed_bf16x3_bytes(int model) { return model == NERF_MODEL_NERF ? Geo<3>::PACKED_BYTES : 0; }
 
 extern "C" int nerf_mlp_pack_bf16(int model, const float* const* params, void* packed, void* stream) {
     NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_pack_bf16: the bf16 mode covers the NeRF model only (model %d)", model);
     NERF_REQUIRE_PTR(params);
     NERF_REQUIRE_PTR(packed);
-    PackBf16Args a;
-    for (int i = 0; i < NERF_NUM_PARAM_TENSORS; ++i) {
-        if (!params[i]) return nerf_fail(NERF_E_NULL, "nerf_mlp_pack_bf16: params[%d] is NULL", i);
-        a.src[i] = params[i];
-    }
-    a.dst = static_cast<unsigned char*>(packed);
-    for (int l = 0; l < NL; ++l) a.layers[l] = LAYERS[l];
-    for (int l = 0; l <= NL; ++l) {
-        a.chunk0[l] = chunk0(l);
-        a.bias_tile0[l] = bias_tile0(l);
-    }
-    const int pieces = NCHUNK * CHUNK_UNITS * 64;
-    pack_bf16_kernel<<<(pieces + 255) / 256, 256, 0, (hipStream_t)stream>>>(a);
-    return nerf_check_launch("nerf_mlp_pack_bf16");
+    return pack_image<1>(params, packed, stream, "nerf_mlp_pack_bf16");
 }
 
-extern "C" int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const float* points, const float* dirs,
-                                 const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray,
-                                 double near, double far, float* colors, float* density, void* stream) {
-    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_fwd_bf16: the bf16 mode covers the NeRF model only (model %d)", model);
-    NERF_REQUIRE(M >= 0, "nerf_mlp_fwd_bf16: M=%lld < 0", (long long)M);
-    if (M == 0) return NERF_OK;
+extern "C" int nerf_mlp_pack_bf16x3(int model, const float* const* params, void* packed, void* stream) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_pack_bf16x3: the bf16x3 mode covers the NeRF model only (model %d)", model);
+    NERF_REQUIRE_PTR(params);
     NERF_REQUIRE_PTR(packed);
-    NERF_REQUIRE_PTR(colors);
-    NERF_REQUIRE_PTR(density);
+    return pack_image<3>(params, packed, stream, "nerf_mlp_pack_bf16x3");
+}
+
+template <int P>
+static int fwd_terms(const char* who, int model, const void* packed, int64_t M, const float* points, const float* dirs,
+                     const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near, double far,
+                     float* colors, float* density, void* stream) {
+    if (model != NERF_MODEL_NERF) return nerf_fail(NERF_E_ARG, "%s: this mode covers the NeRF model only (model %d)", who, model);
+    if (M < 0) return nerf_fail(NERF_E_ARG, "%s: M=%lld < 0", who, (long long)M);
+    if (M == 0) return NERF_OK;
+    if (!packed || !colors || !density) return nerf_fail(NERF_E_NULL, "%s: packed, colors and density must not be NULL", who);
     if (points) {
-        NERF_REQUIRE_PTR(dirs);
+        if (!dirs) return nerf_fail(NERF_E_NULL, "%s: dirs is NULL", who);
     } else {
-        NERF_REQUIRE_PTR(rays_o);
-        NERF_REQUIRE_PTR(rays_d);
-        NERF_REQUIRE_PTR(t);
-        NERF_REQUIRE(S >= 1 && M % S == 0, "nerf_mlp_fwd_bf16: M=%lld is not a multiple of S=%d", (long long)M, S);
-        NERF_REQUIRE(far != near, "nerf_mlp_fwd_bf16: near == far");
+        if (!rays_o || !rays_d || !t) return nerf_fail(NERF_E_NULL, "%s: rays_o, rays_d and t must not be NULL without points", who);
+        if (S < 1 || M % S != 0) return nerf_fail(NERF_E_ARG, "%s: M=%lld is not a multiple of S=%d", who, (long long)M, S);
+        if (far == near) return nerf_fail(NERF_E_ARG, "%s: near == far", who);
     }
-    const int64_t groups = ceil_div64(M, WG_SAMPLES);
-    NERF_REQUIRE(groups < (1ll << 31), "nerf_mlp_fwd_bf16: too many samples");
+    const int64_t groups = ceil_div64(M, Geo<P>::WG_SAMPLES);
+    if (groups >= (1ll << 31)) return nerf_fail(NERF_E_ARG, "%s: too many samples", who);
     Bf16Args a{static_cast<const unsigned char*>(packed), M, points, dirs, rays_o, rays_d, t, S, t_per_ray,
                (float)near, (float)(far - near), colors, density
 #ifdef NERF_DIAG
                , g_bf16_dbg
 #endif
     };
-    if (int rc = nerf_set_lds(nerf_fwd_bf16_kernel, BF16_LDS_BYTES)) return rc;
-    nerf_fwd_bf16_kernel<<<(unsigned)groups, WG_THREADS, BF16_LDS_BYTES, (hipStream_t)stream>>>(a);
-    return nerf_check_launch("nerf_mlp_fwd_bf16");
+    if (int rc = nerf_set_lds(nerf_fwd_bf16_kernel<P>, BF16_LDS_BYTES)) return rc;
+    nerf_fwd_bf16_kernel<P><<<(unsigned)groups, Geo<P>::WG_THREADS, BF16_LDS_BYTES, (hipStream_t)stream>>>(a);
+    return nerf_check_launch(who);
+}
+
+extern "C" int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const float* points, const float* dirs,
+                                 const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray,
+                                 double near, double far, float* colors, float* density, void* stream) {
+    return fwd_terms<1>("nerf_mlp_fwd_bf16", model, packed, M, points, dirs, rays_o, rays_d, t, S, t_per_ray, near, far, colors,
+                        density, stream);
+}
+
+extern "C" int nerf_mlp_fwd_bf16x3(int model, const void* packed, int64_t M, const float* points, const float* dirs,
+                                   const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray,
+                                   double near, double far, float* colors, float* density, void* stream) {
+    return fwd_terms<3>("nerf_mlp_fwd_bf16x3", model, packed, M, points, dirs, rays_o, rays_d, t, S, t_per_ray, near, far, colors,
+                        density, stream);
 }

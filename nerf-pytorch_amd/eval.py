@@ -4,7 +4,7 @@ Poses as reference eval.py:14-41,91-97 (theta sweep, phi = -30 deg, radius 4), r
 on the device, frames quantised as (clip(rgb,0,1)*255) truncated to uint8 (eval.py:149-150) and
 written as PNG.  With torchrun the poses are sharded over ranks (no collective).  A checkpoint of a
 coarse + fine pair (train.py with `num_fine_samples`) is rendered hierarchically; `--precision bf16`
-selects the opt-in bf16 inference kernels (NeRF only)."""
+or `bf16x3` selects the opt-in inference kernels on the bf16 matrix pipe (NeRF only; bf16x3 keeps fp32 accuracy)."""
 import argparse
 import os
 import sys
@@ -66,7 +66,7 @@ def main(argv=None):
     ap.add_argument('--checkpoint', type=str, required=True)
     ap.add_argument('--output', type=str, default='rendered_frames')
     ap.add_argument('--resolution', type=int, default=None, help='override H=W (default: the test image size)')
-    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32')
+    ap.add_argument('--precision', choices=['fp32', 'bf16', 'bf16x3'], default='fp32')
     args = ap.parse_args(argv)
     cfg = parse_config(args.config)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))

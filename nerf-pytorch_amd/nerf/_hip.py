@@ -50,6 +50,9 @@ _SIGS = {
     "nerf_mlp_packed_bf16_bytes": (c_size_t, [c_int]),
     "nerf_mlp_pack_bf16": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
     "nerf_mlp_fwd_bf16": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P, _P, _P]),
+    "nerf_mlp_packed_bf16x3_bytes": (c_size_t, [c_int]),
+    "nerf_mlp_pack_bf16x3": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
+    "nerf_mlp_fwd_bf16x3": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P, _P, _P]),
     "nerf_linear_bwd_workspace_floats": (c_size_t, [c_int64, c_int, c_int]),
     "nerf_linear_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_double, c_double, _P, c_int64, _P, _P]),
     "nerf_linear_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_double, c_double, _P, c_int64, _P, c_int64, c_int,
@@ -283,30 +286,47 @@ def mlp_fwd(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None,
     return colors, density, ws
 
 
-def mlp_pack_bf16(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """bf16 weight image (a uint8 tensor) for mlp_fwd_bf16."""
+def _pack_terms(terms: int, model: int, params: Sequence[torch.Tensor], out: Optional[torch.Tensor]) -> torch.Tensor:
+    name = "bf16" if terms == 1 else "bf16x3"
     if len(params) != NUM_PARAM_TENSORS:
         raise ValueError(f"expected {NUM_PARAM_TENSORS} parameter tensors, got {len(params)}")
-    nbytes = lib.nerf_mlp_packed_bf16_bytes(model)
+    nbytes = getattr(lib, f"nerf_mlp_packed_{name}_bytes")(model)
     if nbytes == 0:
-        raise NotImplementedError("the bf16 inference mode covers the NeRF model only")
-    if out is None:
+        raise NotImplementedError(f"the {name} inference mode covers the NeRF model only")
+    if out is None or out.numel() != nbytes:
         out = torch.empty(nbytes, dtype=torch.uint8, device=params[0].device)
     ptrs = (c_void_p * NUM_PARAM_TENSORS)(*[_dev(p, f"params[{i}]") for i, p in enumerate(params)])
-    _check(lib.nerf_mlp_pack_bf16(model, ptrs, _dev(out, "packed", torch.uint8), _stream()), "nerf_mlp_pack_bf16")
+    _check(getattr(lib, f"nerf_mlp_pack_{name}")(model, ptrs, _dev(out, "packed", torch.uint8), _stream()), f"nerf_mlp_pack_{name}")
     return out
+
+
+def mlp_pack_bf16(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 weight image (a uint8 tensor) for mlp_fwd_bf16."""
+    return _pack_terms(1, model, params, out)
+
+
+def mlp_pack_bf16x3(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Three-term bf16 weight image (a uint8 tensor, three times the bf16 one) for mlp_fwd_bf16."""
+    return _pack_terms(3, model, params, out)
 
 
 def mlp_fwd_bf16(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None, rays_o=None, rays_d=None, t=None,
                  S: int = 0, near: float = 0.0, far: float = 1.0):
+    """Inference forward on the bf16 matrix pipe; the image's size says which of the two modes it was packed for."""
     dev = packed.device
+    if packed.numel() == lib.nerf_mlp_packed_bf16_bytes(model):
+        name = "bf16"
+    elif packed.numel() == lib.nerf_mlp_packed_bf16x3_bytes(model):
+        name = "bf16x3"
+    else:
+        raise ValueError(f"packed image of {packed.numel()} bytes is neither a bf16 nor a bf16x3 image of model {model}")
     colors = torch.empty((M, 3), dtype=torch.float32, device=dev)
     density = torch.empty((M,), dtype=torch.float32, device=dev)
-    ev = timers.start("mlp_fwd_infer_bf16", M)
-    _check(lib.nerf_mlp_fwd_bf16(model, _dev(packed, "packed", torch.uint8), M, _opt(points, "points"),
-                                 _opt(dirs, "dirs"), _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S,
-                                 int(t is not None and t.dim() == 2), float(near), float(far),
-                                 _dev(colors, "colors"), _dev(density, "density"), _stream()), "nerf_mlp_fwd_bf16")
+    ev = timers.start(f"mlp_fwd_infer_{name}", M)
+    _check(getattr(lib, f"nerf_mlp_fwd_{name}")(model, _dev(packed, "packed", torch.uint8), M, _opt(points, "points"),
+                                               _opt(dirs, "dirs"), _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S,
+                                               int(t is not None and t.dim() == 2), float(near), float(far),
+                                               _dev(colors, "colors"), _dev(density, "density"), _stream()), f"nerf_mlp_fwd_{name}")
     timers.stop(ev)
     return colors, density, None
 

@@ -45,17 +45,20 @@ class _FusedMLP(nn.Module):
         self.inference_precision = "fp32"
 
     def set_inference_precision(self, precision: str) -> "_FusedMLP":
-        """'fp32' (default, the parity path) or 'bf16': an opt-in mode for renders without gradients
-        (torch.no_grad() / parameters that do not require grad) in which weights, encodings and
-        activations are rounded to bf16 and accumulated in fp32.  Training always runs fp32."""
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
-        if precision == "bf16":
+        """'fp32' (default, the parity path) or one of two opt-in modes for renders without gradients
+        (torch.no_grad() / parameters that do not require grad) on the bf16 matrix pipe.  'bf16': weights,
+        encodings and activations are rounded to bf16 and accumulated in fp32 (tolerance of its own).
+        'bf16x3': every fp32 operand is split into three bf16 terms and a product is formed from six term
+        products accumulated in fp32 -- fp32 accuracy (it holds the fp32 path's parity bar) at more than twice
+        the fp32 kernel's rate.  Training always runs fp32."""
+        if precision not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'")
+        if precision != "fp32":
             self._check_supported()
             if _hip.lib.nerf_mlp_packed_bf16_bytes(self.model_id) == 0:
-                raise NotImplementedError("the bf16 inference mode covers the NeRF model only")
-            if self._packed_bf16 is None:
-                self._packed_bf16 = PackedWeights(self.model_id, _hip.mlp_pack_bf16)
+                raise NotImplementedError(f"the {precision} inference mode covers the NeRF model only")
+            if self._packed_bf16 is None or precision != self.inference_precision:
+                self._packed_bf16 = PackedWeights(self.model_id, _hip.mlp_pack_bf16 if precision == "bf16" else _hip.mlp_pack_bf16x3)
         self.inference_precision = precision
         return self
 
@@ -67,9 +70,9 @@ class _FusedMLP(nn.Module):
         return ps
 
     def packed_weights(self, train: bool = True) -> torch.Tensor:
-        """Weight image for the kernels: the fp32 image, or the bf16 one for a gradient-free pass of
-        a module switched to bf16 inference."""
-        if not train and self.inference_precision == "bf16":
+        """Weight image for the kernels: the fp32 image, or the bf16 / bf16x3 one for a gradient-free pass of
+        a module switched to that inference mode."""
+        if not train and self.inference_precision != "fp32":
             return self._packed_bf16.get(self.ordered_parameters())
         return self._packed.get(self.ordered_parameters())
 

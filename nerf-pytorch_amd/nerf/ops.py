@@ -34,7 +34,7 @@ class PackedWeights:
 
     def __init__(self, model_id: int, pack=_hip.mlp_pack):
         self.model_id = model_id
-        self._pack = pack      # _hip.mlp_pack (fp32 image) or _hip.mlp_pack_bf16
+        self._pack = pack      # _hip.mlp_pack (fp32 image), _hip.mlp_pack_bf16 or _hip.mlp_pack_bf16x3
         self._key = None
         self._img = None
 
@@ -59,10 +59,10 @@ def wants_grad(params: Sequence[torch.Tensor]) -> bool:
 
 
 def _mlp_fwd(model_id, packed, M, train, **inputs):
-    """The fp32 kernel, or the opt-in bf16 inference kernel when handed a bf16 image (uint8)."""
+    """The fp32 kernel, or an opt-in bf16 / bf16x3 inference kernel when handed such an image (uint8)."""
     if packed.dtype == torch.uint8:
         if train:
-            raise RuntimeError("the bf16 mode is inference-only; training runs the fp32 kernels")
+            raise RuntimeError("the bf16 modes are inference-only; training runs the fp32 kernels")
         return _hip.mlp_fwd_bf16(model_id, packed, M, **inputs)
     return _hip.mlp_fwd(model_id, packed, M, train=train, **inputs)
 

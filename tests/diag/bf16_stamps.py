@@ -7,10 +7,12 @@ import torch
 from nerf import _hip
 from nerf.models import NeRF
 from nerf.rendering import render_nerf
-m = NeRF().cuda().set_inference_precision("bf16")
+PREC = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+m = NeRF().cuda().set_inference_precision(PREC)
 R, S = 4096, 256
 o = torch.randn(R, 3, device="cuda"); d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda"), dim=1)
-nwg = R * S // 256
+WG = 256 if PREC == "bf16" else 128     # samples per workgroup
+nwg = R * S // WG
 dbg = torch.zeros(nwg * 32, dtype=torch.int64, device="cuda")
 _hip.lib.nerf_diag_bf16_stamps.argtypes = [ctypes.c_void_p]
 with torch.no_grad():

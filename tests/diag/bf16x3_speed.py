@@ -1,0 +1,38 @@
+"""Forward-kernel rates of the three inference modes on the same samples: fp32 MFMA, bf16, bf16x3 (three-term split)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "nerf-pytorch_amd"))
+import torch
+from nerf import _hip
+from nerf.models import NeRF
+
+dev = "cuda"
+torch.manual_seed(0)
+m = NeRF().to(dev)
+M = 1 << 20
+x = torch.rand(M, 3, device=dev) * 2 - 1
+d = torch.nn.functional.normalize(torch.randn(M, 3, device=dev), dim=1)
+params = [p.detach() for p in m.parameters()]
+img32 = _hip.mlp_pack(_hip.MODEL_NERF, params)
+img16 = _hip.mlp_pack_bf16(_hip.MODEL_NERF, params)
+img3 = _hip.mlp_pack_bf16x3(_hip.MODEL_NERF, params)
+FLOP = 2 * 658944
+
+
+def run(name, f):
+    out = f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        f()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    print(f"{name:8s} {ms:8.3f} ms  {M / ms / 1e3:8.1f} M samples/s  {M * FLOP / ms / 1e9:7.1f} TFLOP/s (fp32-equivalent)", flush=True)
+    return out
+
+
+c32, s32, _ = run("fp32", lambda: _hip.mlp_fwd(_hip.MODEL_NERF, img32, M, points=x, dirs=d, train=False))
+c16, s16, _ = run("bf16", lambda: _hip.mlp_fwd_bf16(_hip.MODEL_NERF, img16, M, points=x, dirs=d))
+c3, s3, _ = run("bf16x3", lambda: _hip.mlp_fwd_bf16(_hip.MODEL_NERF, img3, M, points=x, dirs=d))
+for name, c, s in (("bf16", c16, s16), ("bf16x3", c3, s3)):
+    print(f"{name:8s} colors rel {float((c - c32).norm() / c32.norm()):.3e} max abs {float((c - c32).abs().max()):.3e}; "
+          f"density rel {float((s - s32).norm() / (s32.norm() + 1e-30)):.3e} max abs {float((s - s32).abs().max()):.3e}")

@@ -164,6 +164,7 @@ def test_device_rays_epoch_semantics(tmp_path):
     ("nerf", "fused", "", []),
     ("siren", "torch", "", []),
     ("nerf", "fused", "num_fine_samples = 16", ["--precision", "bf16"]),   # coarse + fine pair, bf16 inference
+    ("nerf", "fused", "num_fine_samples = 16", ["--precision", "bf16x3"]),  # the same through the three-term kernels
 ])
 def test_train_resume_eval_end_to_end(tmp_path, capsys, model_type, optimizer, extra, eval_args):
     sys.path.insert(0, PKG)

@@ -682,6 +682,52 @@ def test_bf16_render_tolerance_report(hip):
         Siren().to(DEV).set_inference_precision("bf16")
 
 
+@pytest.mark.parametrize("M", [1, 31, 33, 127, 128, 129, 1000, 40000])
+def test_bf16x3_inference_holds_fp32_bar(hip, M):
+    """Opt-in three-term mode (every fp32 operand as three bf16 terms, six term products per product, fp32
+    accumulation; no reference counterpart): same bar as the fp32 kernels against the fp64-accumulating oracle."""
+    model, params = make_model("nerf")
+    g = torch.Generator().manual_seed(1900 + M)
+    x = torch.rand(M, 3, generator=g) * 2 - 1
+    d = torch.randn(M, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    c32, s32 = O.nerf_forward(params, x, d)
+    model.set_inference_precision("bf16x3")
+    with torch.no_grad():
+        c, s = model(x.to(DEV), d.to(DEV))
+    assert rel(c, c32) < RTOL, rel(c, c32)
+    assert rel(s, s32) < RTOL, rel(s, s32)
+    # training never takes this kernel either
+    c_train, _ = model(x.to(DEV), d.to(DEV))
+    assert c_train.requires_grad and rel(c_train, c32) < RTOL
+    model.set_inference_precision("fp32")
+
+
+def test_bf16x3_render_matches_fp32_render(hip):
+    """Rendered image of the three-term mode against the fp32 kernels on the same rays and draws, through the ray-input
+    form of the kernel (positions formed in the kernel) and per-ray depths (the fine pass of a hierarchical render)."""
+    from nerf.rendering import render_nerf, render_nerf_hierarchical
+    model, params = make_model("nerf")
+    fine, _ = make_model("nerf")
+    R, S = 2048, 192
+    o, d = rays(R, 71)
+    o, d = o.to(DEV), d.to(DEV)
+    u = torch.rand(S, generator=torch.Generator().manual_seed(72)).to(DEV)
+    with torch.no_grad():
+        ref = render_nerf(model, o, d, 2.0, 6.0, num_samples=S, device=DEV, chunk_size=1024, u=[u, u])
+        torch.manual_seed(5)
+        ref_h = render_nerf_hierarchical(model, fine, o, d, 2.0, 6.0, 64, 128, device=DEV)
+        model.set_inference_precision("bf16x3")
+        fine.set_inference_precision("bf16x3")
+        out = render_nerf(model, o, d, 2.0, 6.0, num_samples=S, device=DEV, chunk_size=1024, u=[u, u])
+        torch.manual_seed(5)
+        out_h = render_nerf_hierarchical(model, fine, o, d, 2.0, 6.0, 64, 128, device=DEV)
+    assert rel(out, ref) < RTOL, rel(out, ref)
+    # the fine depths are drawn from the coarse weights: an fp32-rounding difference there can move a sample across a
+    # bin edge, so the hierarchical images agree to the rounding-amplified level, not bit for bit
+    assert float((out_h[1] - ref_h[1]).abs().max()) < 1e-4
+
+
 # ----------------------------------------------------------------------------- hierarchical sampling
 def test_sample_pdf_indices_bit_exact(hip):
     """No counterpart in the reference (parity unpinned): checked against the canonical-NeRF
