@@ -126,6 +126,24 @@ __global__ __launch_bounds__(512, 1) void beside(float* out, int mfma_iters, int
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// one wave per SIMD: RUN consecutive MFMAs on one accumulator before moving to the next of 4 (does the order of the 16
+// MFMAs of a K block matter?)
+template <int RUN>
+__global__ __launch_bounds__(256, 1) void runs(float* out, int iters, float x) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+    const float a = x * threadIdx.x, b = x + threadIdx.x;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc[(u / RUN) & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[(u / RUN) & 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) s += acc[i][k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <typename F>
 float timed(F launch) {
     hipEvent_t e0, e1;
@@ -139,6 +157,9 @@ float timed(F launch) {
 int main() {
     float* out;
     CK(hipMalloc(&out, 256 * 512 * 4));
+    printf("fp32 MFMA, runs on one accumulator: 1 %.3f ms, 2 %.3f ms, 4 %.3f ms, 16 %.3f ms (320,000 MFMAs per wave)\n",
+           timed([&] { runs<1><<<256, 256>>>(out, 20000, 1e-3f); }), timed([&] { runs<2><<<256, 256>>>(out, 20000, 1e-3f); }),
+           timed([&] { runs<4><<<256, 256>>>(out, 20000, 1e-3f); }), timed([&] { runs<16><<<256, 256>>>(out, 20000, 1e-3f); }));
     const int mi = 20000, vi = 20000;   // 320,000 MFMAs (64 cycles each) / 1,280,000 FMAs (4 cycles each) per wave: 20.5 M cycles each
     const float tm = timed([&] { roles<1><<<256, 512>>>(out, mi, vi, 1e-3f); });
     const float tv = timed([&] { roles<2><<<256, 512>>>(out, mi, vi, 1e-3f); });
