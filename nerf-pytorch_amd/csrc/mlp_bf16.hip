@@ -1,4 +1,4 @@
-// Opt-in bf16 inference forward of the NeRF MLP (nerf/models.py:62-75): bf16 operands, fp32
+// Opt-in inference forwards on the bf16 matrix pipe.  One-term mode, NeRF MLP (nerf/models.py:62-75): bf16 operands, fp32
 // accumulation on v_mfma_f32_32x32x16_bf16.  The fp32 kernels in mlp_fwd.hip stay the default and
 // the parity path; this one trades accuracy (bf16 rounding of every weight and activation,
 // tolerance stated by its tests) for matrix-core throughput.
@@ -29,6 +29,8 @@
 // mode holds the fp32 parity bar, unlike the one-term mode.  The weight image stores the three terms of an A fragment
 // as three consecutive units; a wave keeps three B fragments per k-step (192 registers of activations), which is why a
 // workgroup is 4 waves of 512 registers here instead of 8 waves of 256; encodings use the fp32 path's sincos.
+// This variant also covers the Siren model (nerf/models.py:185-203): its sine activations are applied to the fp32
+// accumulators before the split, which the one-term mode could not do usefully (sin(30 z) of bf16-rounded inputs).
 #include "mlp_device.h"
 
 #include <utility>
@@ -47,51 +49,76 @@ constexpr int CHUNK_BYTES = CHUNK_UNITS * UNIT_BYTES;
 constexpr int NBUF = 4;
 
 // ---- layer table -------------------------------------------------------------------------
-enum Enc { ENC_NONE = 0, ENC_PE = 1, ENC_DE = 2 };
+enum Enc { ENC_NONE = 0, ENC_PE = 1, ENC_DE = 2, ENC_XYZ = 3 };
 struct LayerInfo {
     int n_ot;      // 32-row output tiles
     int nks_acc;   // k-steps fed by the previous layer's accumulators (16 features each)
-    int enc;       // extra k-steps fed by an encoding: ENC_PE 4, ENC_DE 2
+    int enc;       // extra k-steps fed by an encoding: ENC_PE 4, ENC_DE 2, ENC_XYZ 1 (the raw coordinates)
     int n_out;     // valid output rows
     int n_in;      // valid accumulator-fed inputs (also the column where the encoding part starts)
     int ld;        // row pitch of the [out, in] weight tensor
     int wtensor;   // state_dict index of the weight; the bias follows it
+    int last_row_tensor;   // >= 0: output row n_out-1 is row 0 of this [1, ld] weight (its bias follows it)
 };
-constexpr int NL = 12;
-constexpr LayerInfo LAYERS[NL] = {
-    {8, 0, ENC_PE, 256, 0, 63, 0},      {8, 16, ENC_NONE, 256, 256, 256, 2},  {8, 16, ENC_NONE, 256, 256, 256, 4},
-    {8, 16, ENC_NONE, 256, 256, 256, 6}, {8, 16, ENC_NONE, 256, 256, 256, 8},  {8, 16, ENC_PE, 256, 256, 319, 10},
-    {8, 16, ENC_NONE, 256, 256, 256, 12}, {8, 16, ENC_NONE, 256, 256, 256, 14}, {8, 16, ENC_NONE, 256, 256, 256, 16},
-    {9, 16, ENC_NONE, 257, 256, 256, 18}, {4, 16, ENC_DE, 128, 256, 283, 20},   {1, 8, ENC_NONE, 3, 128, 128, 22},
+constexpr int NL_MAX = 12;
+template <int MODEL> struct Net;
+// nerf/models.py:62-75.  block2.8 (257 rows: 256 features + the density row) is one layer of nine tiles.
+template <> struct Net<NERF_MODEL_NERF> {
+    static constexpr int NL = 12;
+    static constexpr LayerInfo LAYERS[NL_MAX] = {
+        {8, 0, ENC_PE, 256, 0, 63, 0, -1},      {8, 16, ENC_NONE, 256, 256, 256, 2, -1},  {8, 16, ENC_NONE, 256, 256, 256, 4, -1},
+        {8, 16, ENC_NONE, 256, 256, 256, 6, -1}, {8, 16, ENC_NONE, 256, 256, 256, 8, -1},  {8, 16, ENC_PE, 256, 256, 319, 10, -1},
+        {8, 16, ENC_NONE, 256, 256, 256, 12, -1}, {8, 16, ENC_NONE, 256, 256, 256, 14, -1}, {8, 16, ENC_NONE, 256, 256, 256, 16, -1},
+        {9, 16, ENC_NONE, 257, 256, 256, 18, -1}, {4, 16, ENC_DE, 128, 256, 283, 20, -1},   {1, 8, ENC_NONE, 3, 128, 128, 22, -1},
+    };
 };
-constexpr int enc_ks(int enc) { return enc == ENC_PE ? 4 : enc == ENC_DE ? 2 : 0; }
-constexpr int layer_ks(int l) { return LAYERS[l].nks_acc + enc_ks(LAYERS[l].enc); }
-constexpr int bias_tile0(int l) {
-    int t = 0;
-    for (int i = 0; i < l; ++i) t += LAYERS[i].n_ot;
-    return t;
-}
-constexpr int NBIAS_TILES = bias_tile0(NL);
-constexpr size_t BIAS_FLOATS = (size_t)NBIAS_TILES * 32;
+// nerf/models.py:185-203.  feature_remap (256 rows) and density_branch (1 row) both read the last sine layer: one
+// layer of nine tiles whose 257th row comes from the density branch's tensors.
+template <> struct Net<NERF_MODEL_SIREN> {
+    static constexpr int NL = 11;
+    static constexpr LayerInfo LAYERS[NL_MAX] = {
+        {8, 0, ENC_XYZ, 256, 0, 3, 0, -1},       {8, 16, ENC_NONE, 256, 256, 256, 2, -1},  {8, 16, ENC_NONE, 256, 256, 256, 4, -1},
+        {8, 16, ENC_NONE, 256, 256, 256, 6, -1}, {8, 16, ENC_NONE, 256, 256, 256, 8, -1},  {8, 16, ENC_NONE, 256, 256, 256, 10, -1},
+        {8, 16, ENC_NONE, 256, 256, 256, 12, -1}, {8, 16, ENC_NONE, 256, 256, 256, 14, -1}, {9, 16, ENC_NONE, 257, 256, 256, 18, 16},
+        {4, 16, ENC_DE, 128, 256, 283, 20, -1},   {1, 8, ENC_NONE, 3, 128, 128, 22, -1},    {0, 0, ENC_NONE, 0, 0, 0, 0, -1},
+    };
+};
+constexpr int enc_ks(int enc) { return enc == ENC_PE ? 4 : enc == ENC_DE ? 2 : enc == ENC_XYZ ? 1 : 0; }
+constexpr int NBIAS_TILES_MAX = 86;                        // LDS room for the bias image of either model
 
-// Geometry of the P-term kernel: P units (one per term) for every A fragment, every layer starts a new chunk.
-template <int P>
+// Geometry of the P-term kernel of a model: P units (one per term) for every A fragment, every layer starts a new chunk.
+constexpr int wg_threads(int P) { return P == 1 ? 512 : 256; }
+constexpr int per_chunk(int P) { return CHUNK_BYTES / (16 * wg_threads(P)); }   // LDS-DMA instructions per thread and chunk
+template <int P, int MODEL>
 struct Geo {
-    static constexpr int WG_THREADS = P == 1 ? 512 : 256;
+    using N = Net<MODEL>;
+    static constexpr int NL = N::NL;
+    static constexpr int WG_THREADS = wg_threads(P);
     static constexpr int WG_SAMPLES = WG_THREADS / 2;                        // a wave owns 32 samples
-    static constexpr int PER_CHUNK = CHUNK_BYTES / (16 * WG_THREADS);        // LDS-DMA instructions per thread and chunk
-    static constexpr int layer_units(int l) { return P * LAYERS[l].n_ot * layer_ks(l); }
+    static constexpr int PER_CHUNK = per_chunk(P);
+    static constexpr int layer_ks(int l) { return N::LAYERS[l].nks_acc + enc_ks(N::LAYERS[l].enc); }
+    static constexpr int layer_units(int l) { return P * N::LAYERS[l].n_ot * layer_ks(l); }
     static constexpr int layer_chunks(int l) { return (layer_units(l) + CHUNK_UNITS - 1) / CHUNK_UNITS; }
     static constexpr int chunk0(int l) {
         int c = 0;
         for (int i = 0; i < l; ++i) c += layer_chunks(i);
         return c;
     }
+    static constexpr int bias_tile0(int l) {
+        int t = 0;
+        for (int i = 0; i < l; ++i) t += N::LAYERS[i].n_ot;
+        return t;
+    }
     static constexpr int NCHUNK = chunk0(NL);
+    static constexpr int NBIAS_TILES = bias_tile0(NL);
+    static constexpr size_t BIAS_FLOATS = (size_t)NBIAS_TILES * 32;
     static constexpr size_t IMG_BYTES = (size_t)NCHUNK * CHUNK_BYTES;
     static constexpr size_t PACKED_BYTES = IMG_BYTES + BIAS_FLOATS * 4;
 };
-static_assert(Geo<1>::NCHUNK == 43 && Geo<3>::NCHUNK == 124 && NBIAS_TILES == 86, "bf16 image layout");
+static_assert(Geo<1, NERF_MODEL_NERF>::NCHUNK == 43 && Geo<3, NERF_MODEL_NERF>::NCHUNK == 124 &&
+                  Geo<1, NERF_MODEL_NERF>::NBIAS_TILES == 86 && Geo<3, NERF_MODEL_SIREN>::NBIAS_TILES == 78 &&
+                  Geo<3, NERF_MODEL_SIREN>::NBIAS_TILES <= NBIAS_TILES_MAX,
+              "bf16 image layout");
 
 // term `plane` of the three-term bf16 expansion of x (term 0 alone is the plain bf16 rounding)
 __host__ __device__ inline __bf16 bf16_term(float x, int plane) {
@@ -111,6 +138,7 @@ __host__ __device__ inline int k_column(const LayerInfo& L, int ks, int h, int j
     }
     // encoding slots: lane half h owns half of the frequencies, so both halves run the same code
     const int e = 8 * (ks - L.nks_acc) + j;
+    if (L.enc == ENC_XYZ) return (h == 0 && e < 3) ? L.n_in + e : -1;
     if (L.enc == ENC_PE) {  // nerf/encoding.py column order: x | sin(2^f x) cos(2^f x) blocks of 3
         if (e < 30) return L.n_in + 3 + 6 * (5 * h + e / 6) + e % 6;
         if (e == 30) return L.n_in + (h ? 2 : 0);
@@ -124,22 +152,22 @@ __host__ __device__ inline int k_column(const LayerInfo& L, int ks, int h, int j
 struct PackBf16Args {
     const float* src[NERF_NUM_PARAM_TENSORS];
     unsigned char* dst;
-    LayerInfo layers[NL];
-    int chunk0[NL + 1];
-    int bias_tile0[NL + 1];
+    LayerInfo layers[NL_MAX];
+    int chunk0[NL_MAX + 1];
+    int bias_tile0[NL_MAX + 1];
 };
 
-template <int P>
+template <int P, int MODEL>
 __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBf16Args a) {
-    constexpr int NCHUNK = Geo<P>::NCHUNK;
-    constexpr size_t IMG_BYTES = Geo<P>::IMG_BYTES;
+    constexpr int NCHUNK = Geo<P, MODEL>::NCHUNK, NBIAS_TILES = Geo<P, MODEL>::NBIAS_TILES;
+    constexpr size_t IMG_BYTES = Geo<P, MODEL>::IMG_BYTES;
     const int p = blockIdx.x * 256 + threadIdx.x;  // one 16-byte piece: unit, lane
     if (p < NCHUNK * CHUNK_UNITS * 64) {
         const int chunk = p / (CHUNK_UNITS * 64), unit = (p / 64) % CHUNK_UNITS, lane = p & 63;
         int l = 0;
         while (chunk >= a.chunk0[l + 1]) ++l;
         const LayerInfo L = a.layers[l];
-        const int nks = L.nks_acc + (L.enc == ENC_PE ? 4 : L.enc == ENC_DE ? 2 : 0);
+        const int nks = L.nks_acc + enc_ks(L.enc);
         const int up = (chunk - a.chunk0[l]) * CHUNK_UNITS + unit;
         const int plane = up % P, u = up / P;       // the P terms of a fragment are consecutive units
         bf16x8 v;
@@ -149,7 +177,8 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBf16Args a) {
             const int ks = u / L.n_ot, ot = u % L.n_ot;
             const int out = 32 * ot + (lane & 31), h = lane >> 5;
             if (out < L.n_out) {
-                const float* __restrict__ w = a.src[L.wtensor] + (size_t)out * L.ld;
+                const float* __restrict__ w = (L.last_row_tensor >= 0 && out == L.n_out - 1)
+                                                  ? a.src[L.last_row_tensor] : a.src[L.wtensor] + (size_t)out * L.ld;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int col = k_column(L, ks, h, j);
@@ -166,7 +195,9 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBf16Args a) {
         while (tile >= a.bias_tile0[l + 1]) ++l;
         const LayerInfo L = a.layers[l];
         const int out = 32 * (tile - a.bias_tile0[l]) + (g & 3) + 8 * (g >> 2) + 4 * h;
-        reinterpret_cast<float*>(a.dst + IMG_BYTES)[p] = out < L.n_out ? a.src[L.wtensor + 1][out] : 0.0f;
+        float b = 0.0f;
+        if (out < L.n_out) b = (L.last_row_tensor >= 0 && out == L.n_out - 1) ? a.src[L.last_row_tensor + 1][0] : a.src[L.wtensor + 1][out];
+        reinterpret_cast<float*>(a.dst + IMG_BYTES)[p] = b;
     }
 }
 
@@ -200,7 +231,7 @@ struct Bf16Args {
 #define DIAG_STAMP(i) ((void)0)
 #endif
 
-constexpr int BF16_LDS_BYTES = NBUF * CHUNK_BYTES + (int)BIAS_FLOATS * 4;
+constexpr int BF16_LDS_BYTES = NBUF * CHUNK_BYTES + NBIAS_TILES_MAX * 32 * 4;
 
 struct Ring {
     const unsigned char* img;
@@ -208,7 +239,7 @@ struct Ring {
     int next;        // chunk the next begin_chunk() hands out
     unsigned voff;   // this thread's byte offset inside a slice of a chunk (16 * tid)
     int wave;
-    int nchunk, img_bytes, per_chunk, wg_threads;   // Geo<P> of the kernel (compile-time constants after inlining)
+    int nchunk, img_bytes, per_chunk, wg_threads;   // Geo<P, MODEL> of the kernel (compile-time constants after inlining)
 };
 
 // piece i (16 bytes per thread) of a chunk: global memory -> LDS without staging registers
@@ -239,7 +270,7 @@ __device__ __forceinline__ void ring_issue(const Ring& r, int chunk) {
 template <int P, int REM>
 __device__ __forceinline__ void ring_publish_next(Ring& r) {
     if constexpr (REM >= 1) {
-        if constexpr (REM >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Geo<P>::PER_CHUNK) : "memory");
+        if constexpr (REM >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(per_chunk(P)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -287,7 +318,7 @@ __device__ __forceinline__ void mma_layer16(Ring& r, int lane, f32x16 (&acc)[9],
     constexpr int NKS = NKS_A + NKS_E, UNITS = P * NOT * NKS, CHUNKS = (UNITS + CHUNK_UNITS - 1) / CHUNK_UNITS;
     constexpr int PF = 4;            // fragment reads in flight (8 measure the same in both kernels)
     constexpr int PUBLISH_AT = PF;   // unit of a chunk at whose fetch the next chunk is published
-    constexpr int PER_CHUNK = Geo<P>::PER_CHUNK;
+    constexpr int PER_CHUNK = per_chunk(P);
     static_assert(UNITS >= PF && (UNITS % CHUNK_UNITS == 0 || UNITS % CHUNK_UNITS >= PUBLISH_AT + PER_CHUNK), "chunk too short");
     const unsigned char* buf = nullptr;
     bf16x8 a[PF];
@@ -340,9 +371,14 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned (&w)[P]) {
     }
 }
 
-// accumulator tiles -> B fragments of the next layer (two k-steps per 32-feature tile)
-template <int P, int NFT, bool RELU>
+// accumulator tiles -> B fragments of the next layer (two k-steps per 32-feature tile), through the layer's activation:
+// FR_SIN is sin(z) of a hidden sine layer (nerf/models.py:89-90 with w0 = 1; the argument is bounded like the fp32 kernel's),
+// FR_SIN30 the first sine layer's sin(30 z).  The sine variants exist for the three-term kernel only.
+enum FragAct { FR_NONE = 0, FR_RELU = 1, FR_SIN = 2, FR_SIN30 = 3 };
+template <int P, int NFT, int ACT>
 __device__ __forceinline__ void to_frags(const f32x16 (&acc)[9], bf16x8 (&X)[P][16]) {
+    constexpr bool RELU = ACT == FR_RELU;
+    static_assert(P > 1 || ACT == FR_NONE || ACT == FR_RELU, "sine layers need the three-term kernel");
 #pragma unroll
     for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
@@ -360,6 +396,18 @@ __device__ __forceinline__ void to_frags(const f32x16 (&acc)[9], bf16x8 (&X)[P][
                     if (RELU) {   // (fmaxf puts a canonicalising v_max v, v, v in front of the v_max)
                         asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
                         asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+                    }
+                    if constexpr (ACT == FR_SIN || ACT == FR_SIN30) {
+                        float c;
+                        if constexpr (ACT == FR_SIN30) {
+                            // the reduction without the library's large-argument path (128 inlined copies of it otherwise):
+                            // exact to 1e5 rad, i.e. for first-layer pre-activations up to 3300 -- coordinates are in [-1, 1]
+                            nerf_sincosf_bounded(mul_rn(30.0f, v0), &v0, &c);
+                            nerf_sincosf_bounded(mul_rn(30.0f, v1), &v1, &c);
+                        } else {
+                            nerf_sincosf_bounded(v0, &v0, &c);
+                            nerf_sincosf_bounded(v1, &v1, &c);
+                        }
                     }
                     unsigned t[P];
                     split2<P>(v0, v1, t);
@@ -412,10 +460,11 @@ __device__ __forceinline__ float norm_coord16(float p, float nearf, float spanf)
     return sub_rn(div_rn(mul_rn(2.0f, sub_rn(p, nearf)), spanf), 1.0f);
 }
 
-template <int P>
-__global__ __launch_bounds__(Geo<P>::WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf16Args a) {
-    using G = Geo<P>;
+template <int P, int MODEL>
+__global__ __launch_bounds__(wg_threads(P), 1) void fwd_bf16_kernel(Bf16Args a) {
+    using G = Geo<P, MODEL>;
     constexpr int WG_THREADS = G::WG_THREADS, WG_SAMPLES = G::WG_SAMPLES, PER_CHUNK = G::PER_CHUNK;
+    constexpr auto bias_tile0 = [](int l) { return G::bias_tile0(l); };
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     float* bias_lds = reinterpret_cast<float*>(smem + NBUF * CHUNK_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -426,7 +475,7 @@ __global__ __launch_bounds__(Geo<P>::WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf
     // Ordinary loads first (inputs, bias image -> LDS): once LDS-DMA loads are in flight the compiler
     // waits for ALL of them at the first use of an ordinary load's result.
     const float* bias_g = reinterpret_cast<const float*>(a.img + G::IMG_BYTES);
-    for (int i = tid; i < (int)BIAS_FLOATS; i += WG_THREADS) bias_lds[i] = bias_g[i];
+    for (int i = tid; i < (int)G::BIAS_FLOATS; i += WG_THREADS) bias_lds[i] = bias_g[i];
 
     // both lane halves load the sample of lane & 31
     const size_t m = (size_t)blockIdx.x * WG_SAMPLES + wave * 32 + (lane & 31);
@@ -458,10 +507,10 @@ __global__ __launch_bounds__(Geo<P>::WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf
     ring_issue(ring, 2);
     __builtin_amdgcn_sched_barrier(0);
 
-    // encodings in the slot order k_column() gives the weight image: half h owns frequencies
-    // 5h..5h+4 of the position and 2h..2h+1 of the direction, the raw coordinates fill the tail
-    bf16x8 PE[P][4];
-    {
+    // First layer's encoding fragments in the slot order k_column() gives the weight image.  NeRF: lane half h owns
+    // frequencies 5h..5h+4 of the position, the raw coordinates fill the tail.  Siren: the raw coordinates, half 0.
+    bf16x8 E0[P][4];
+    if constexpr (MODEL == NERF_MODEL_NERF) {
         float v[32];
         const float s0 = h ? 32.0f : 1.0f;
 #pragma unroll
@@ -476,7 +525,12 @@ __global__ __launch_bounds__(Geo<P>::WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf
         }
         v[30] = h ? x[2] : x[0];
         v[31] = h ? 0.0f : x[1];
-        vals_to_frags<P, 32>(v, PE);
+        vals_to_frags<P, 32>(v, E0);
+    } else {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = h ? 0.0f : x[c];
+        vals_to_frags<P, 8>(v, E0);
     }
     // publish chunk 0 and the bias image: own pieces of chunk 0 landed (chunks 1, 2 stay in flight),
     // own LDS writes done, then the barrier
@@ -487,40 +541,10 @@ __global__ __launch_bounds__(Geo<P>::WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf
 
     f32x16 acc[9];
     bf16x8 X[P][16];
-
-    init_bias<8>(acc, bias_lds, bias_tile0(0), h);
-    mma_layer16<P, 8, 0, 4, 2>(ring, lane, acc, X, PE);
-    to_frags<P, 8, true>(acc, X);
-    DIAG_STAMP(2);
-#pragma unroll 1
-    for (int l = 1; l <= 4; ++l) {
-        init_bias<8>(acc, bias_lds, 8 * l, h);
-        DIAG_STAMP(10 + 3 * (l - 1));
-        mma_layer16<P, 8, 16, 0, 2>(ring, lane, acc, X, PE);
-        DIAG_STAMP(11 + 3 * (l - 1));
-        to_frags<P, 8, true>(acc, X);
-        DIAG_STAMP(12 + 3 * (l - 1));
-    }
-    DIAG_STAMP(3);
-    // skip layer: [features | position encoding]
-    init_bias<8>(acc, bias_lds, bias_tile0(5), h);
-    mma_layer16<P, 8, 16, 4, 2>(ring, lane, acc, X, PE);
-    to_frags<P, 8, true>(acc, X);
-#pragma unroll 1
-    for (int l = 6; l <= 8; ++l) {
-        init_bias<8>(acc, bias_lds, 8 * l, h);
-        mma_layer16<P, 8, 16, 0, 2>(ring, lane, acc, X, PE);
-        to_frags<P, 8, true>(acc, X);
-    }
-    // block2.8: 256 feature rows (no activation) + the density row (first row of the ninth tile)
-    init_bias<9>(acc, bias_lds, bias_tile0(9), h);
-    mma_layer16<P, 9, 16, 0, 2>(ring, lane, acc, X, PE);
-    const float dens = fmaxf(acc[8][0], 0.0f);
-    to_frags<P, 8, false>(acc, X);
-    // rgb head: [features | direction encoding] -> 128, ReLU.  The direction encoding is only
-    // computed now: its registers would otherwise be held through the whole trunk.
-    bf16x8 DE[P][4];
-    {
+    // direction encoding (both models: nerf/encoding.py with 4 frequencies): half h owns frequencies 2h..2h+1, the raw
+    // direction sits behind them in half 0.  Only computed in front of the layer that reads it: its registers would
+    // otherwise be held through the whole trunk.
+    auto direction_frags = [&](bf16x8 (&DE)[P][4]) {
         float v[16];
         const float s0 = h ? 4.0f : 1.0f;
 #pragma unroll
@@ -537,12 +561,73 @@ __global__ __launch_bounds__(Geo<P>::WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf
         for (int c = 0; c < 3; ++c) v[12 + c] = h ? 0.0f : d[c];
         v[15] = 0.0f;
         vals_to_frags<P, 16>(v, DE);
+    };
+    float dens;
+
+    if constexpr (MODEL == NERF_MODEL_NERF) {
+        init_bias<8>(acc, bias_lds, bias_tile0(0), h);
+        mma_layer16<P, 8, 0, 4, 2>(ring, lane, acc, X, E0);
+        to_frags<P, 8, FR_RELU>(acc, X);
+        DIAG_STAMP(2);
+#pragma unroll 1
+        for (int l = 1; l <= 4; ++l) {
+            init_bias<8>(acc, bias_lds, 8 * l, h);
+            DIAG_STAMP(10 + 3 * (l - 1));
+            mma_layer16<P, 8, 16, 0, 2>(ring, lane, acc, X, E0);
+            DIAG_STAMP(11 + 3 * (l - 1));
+            to_frags<P, 8, FR_RELU>(acc, X);
+            DIAG_STAMP(12 + 3 * (l - 1));
+        }
+        DIAG_STAMP(3);
+        // skip layer: [features | position encoding]
+        init_bias<8>(acc, bias_lds, bias_tile0(5), h);
+        mma_layer16<P, 8, 16, 4, 2>(ring, lane, acc, X, E0);
+        to_frags<P, 8, FR_RELU>(acc, X);
+#pragma unroll 1
+        for (int l = 6; l <= 8; ++l) {
+            init_bias<8>(acc, bias_lds, 8 * l, h);
+            mma_layer16<P, 8, 16, 0, 2>(ring, lane, acc, X, E0);
+            to_frags<P, 8, FR_RELU>(acc, X);
+        }
+        // block2.8: 256 feature rows (no activation) + the density row (first row of the ninth tile)
+        init_bias<9>(acc, bias_lds, bias_tile0(9), h);
+        mma_layer16<P, 9, 16, 0, 2>(ring, lane, acc, X, E0);
+        dens = fmaxf(acc[8][0], 0.0f);
+        to_frags<P, 8, FR_NONE>(acc, X);
+        // rgb head: [features | direction encoding] -> 128, ReLU
+        bf16x8 DE[P][4];
+        direction_frags(DE);
+        init_bias<4>(acc, bias_lds, bias_tile0(10), h);
+        mma_layer16<P, 4, 16, 2, 1>(ring, lane, acc, X, DE);
+        to_frags<P, 4, FR_RELU>(acc, X);
+        init_bias<1>(acc, bias_lds, bias_tile0(11), h);
+        mma_layer16<P, 1, 8, 0, 0>(ring, lane, acc, X, DE);
+    } else {
+        // nerf/models.py:185-203: sin(30 (W0 x + b0)), seven sin(W h + b) layers, then feature_remap + density_branch
+        // as one nine-tile layer, the 283 -> 128 sine layer of the rgb head and its 128 -> 3 output layer
+        init_bias<8>(acc, bias_lds, bias_tile0(0), h);
+        mma_layer16<P, 8, 0, 1, 2>(ring, lane, acc, X, E0);
+        to_frags<P, 8, FR_SIN30>(acc, X);
+        DIAG_STAMP(2);
+#pragma unroll 1
+        for (int l = 1; l <= 7; ++l) {
+            init_bias<8>(acc, bias_lds, 8 * l, h);
+            mma_layer16<P, 8, 16, 0, 2>(ring, lane, acc, X, E0);
+            to_frags<P, 8, FR_SIN>(acc, X);
+        }
+        DIAG_STAMP(3);
+        init_bias<9>(acc, bias_lds, bias_tile0(8), h);
+        mma_layer16<P, 9, 16, 0, 2>(ring, lane, acc, X, E0);
+        dens = fmaxf(acc[8][0], 0.0f) * 10.0f;           // relu(sigma) * sigma_mul (models.py:193)
+        to_frags<P, 8, FR_NONE>(acc, X);
+        bf16x8 DE[P][4];
+        direction_frags(DE);
+        init_bias<4>(acc, bias_lds, bias_tile0(9), h);
+        mma_layer16<P, 4, 16, 2, 1>(ring, lane, acc, X, DE);
+        to_frags<P, 4, FR_SIN>(acc, X);
+        init_bias<1>(acc, bias_lds, bias_tile0(10), h);
+        mma_layer16<P, 1, 8, 0, 0>(ring, lane, acc, X, DE);
     }
-    init_bias<4>(acc, bias_lds, bias_tile0(10), h);
-    mma_layer16<P, 4, 16, 2, 1>(ring, lane, acc, X, DE);
-    to_frags<P, 4, true>(acc, X);
-    init_bias<1>(acc, bias_lds, bias_tile0(11), h);
-    mma_layer16<P, 1, 8, 0, 0>(ring, lane, acc, X, DE);
 
     DIAG_STAMP(4);
     if (valid && h == 0) {  // rows 0..2 of the last tile and the density row sit in lane half 0
@@ -553,54 +638,45 @@ __global__ __launch_bounds__(Geo<P>::WG_THREADS, 1) void nerf_fwd_bf16_kernel(Bf
     DIAG_STAMP(5);
 }
 
-template <int P>
+template <int P, int MODEL>
 int pack_image(const float* const* params, void* packed, void* stream, const char* who) {
-    using G = Geo<P>;
+    using G = Geo<P, MODEL>;
     PackBf16Args a;
     for (int i = 0; i < NERF_NUM_PARAM_TENSORS; ++i) {
         if (!params[i]) return nerf_fail(NERF_E_NULL, "%s: params[%d] is NULL", who, i);
         a.src[i] = params[i];
     }
     a.dst = static_cast<unsigned char*>(packed);
-    for (int l = 0; l < NL; ++l) a.layers[l] = LAYERS[l];
-    for (int l = 0; l <= NL; ++l) {
-        a.chunk0[l] = G::chunk0(l);
-        a.bias_tile0[l] = bias_tile0(l);
+    for (int l = 0; l < NL_MAX; ++l) a.layers[l] = Net<MODEL>::LAYERS[l];
+    for (int l = 0; l <= NL_MAX; ++l) {
+        a.chunk0[l] = G::chunk0(l < G::NL ? l : G::NL);
+        a.bias_tile0[l] = G::bias_tile0(l < G::NL ? l : G::NL);
     }
     const int pieces = G::NCHUNK * CHUNK_UNITS * 64;
-    pack_bf16_kernel<P><<<(pieces + 255) / 256, 256, 0, (hipStream_t)stream>>>(a);
+    pack_bf16_kernel<P, MODEL><<<(pieces + 255) / 256, 256, 0, (hipStream_t)stream>>>(a);
     return nerf_check_launch(who);
 }
 
-}  // namespace
+template <int P, int MODEL>
+int launch_fwd(const Bf16Args& a, int64_t M, void* stream, const char* who) {
+    const int64_t groups = ceil_div64(M, Geo<P, MODEL>::WG_SAMPLES);
+    if (groups >= (1ll << 31)) return nerf_fail(NERF_E_ARG, "%s: too many samples", who);
+    if (int rc = nerf_set_lds(fwd_bf16_kernel<P, MODEL>, BF16_LDS_BYTES)) return rc;
+    fwd_bf16_kernel<P, MODEL><<<(unsigned)groups, wg_threads(P), BF16_LDS_BYTES, (hipStream_t)stream>>>(a);
+    return nerf_check_launch(who);
+}
 
 #ifdef NERF_DIAG
-static unsigned long long* g_bf16_dbg = nullptr;
-extern "C" void nerf_diag_bf16_stamps(unsigned long long* device_buffer) { g_bf16_dbg = device_buffer; }
+unsigned long long* g_bf16_dbg = nullptr;
 #endif
 
-extern "C" size_t nerf_mlp_packed_bf16_bytes(int model) { return model == NERF_MODEL_NERF ? Geo<1>::PACKED_BYTES : 0; }
-extern "C" size_t nerf_mlp_packed_bf16x3_bytes(int model) { return model == NERF_MODEL_NERF ? Geo<3>::PACKED_BYTES : 0; }
-
-extern "C" int nerf_mlp_pack_bf16(int model, const float* const* params, void* packed, void* stream) {
-    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_pack_bf16: the bf16 mode covers the NeRF model only (model %d)", model);
-    NERF_REQUIRE_PTR(params);
-    NERF_REQUIRE_PTR(packed);
-    return pack_image<1>(params, packed, stream, "nerf_mlp_pack_bf16");
-}
-
-extern "C" int nerf_mlp_pack_bf16x3(int model, const float* const* params, void* packed, void* stream) {
-    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_pack_bf16x3: the bf16x3 mode covers the NeRF model only (model %d)", model);
-    NERF_REQUIRE_PTR(params);
-    NERF_REQUIRE_PTR(packed);
-    return pack_image<3>(params, packed, stream, "nerf_mlp_pack_bf16x3");
-}
-
+// P = 1: the NeRF model only (sin(30 z) of bf16-rounded inputs is no usable Siren); P = 3: both models
 template <int P>
-static int fwd_terms(const char* who, int model, const void* packed, int64_t M, const float* points, const float* dirs,
-                     const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near, double far,
-                     float* colors, float* density, void* stream) {
-    if (model != NERF_MODEL_NERF) return nerf_fail(NERF_E_ARG, "%s: this mode covers the NeRF model only (model %d)", who, model);
+int fwd_terms(const char* who, int model, const void* packed, int64_t M, const float* points, const float* dirs,
+              const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near, double far,
+              float* colors, float* density, void* stream) {
+    if (!(model == NERF_MODEL_NERF || (P == 3 && model == NERF_MODEL_SIREN)))
+        return nerf_fail(NERF_E_ARG, P == 1 ? "%s: the bf16 mode covers the NeRF model only (model %d)" : "%s: unknown model %d", who, model);
     if (M < 0) return nerf_fail(NERF_E_ARG, "%s: M=%lld < 0", who, (long long)M);
     if (M == 0) return NERF_OK;
     if (!packed || !colors || !density) return nerf_fail(NERF_E_NULL, "%s: packed, colors and density must not be NULL", who);
@@ -611,17 +687,43 @@ static int fwd_terms(const char* who, int model, const void* packed, int64_t M, 
         if (S < 1 || M % S != 0) return nerf_fail(NERF_E_ARG, "%s: M=%lld is not a multiple of S=%d", who, (long long)M, S);
         if (far == near) return nerf_fail(NERF_E_ARG, "%s: near == far", who);
     }
-    const int64_t groups = ceil_div64(M, Geo<P>::WG_SAMPLES);
-    if (groups >= (1ll << 31)) return nerf_fail(NERF_E_ARG, "%s: too many samples", who);
     Bf16Args a{static_cast<const unsigned char*>(packed), M, points, dirs, rays_o, rays_d, t, S, t_per_ray,
                (float)near, (float)(far - near), colors, density
 #ifdef NERF_DIAG
                , g_bf16_dbg
 #endif
     };
-    if (int rc = nerf_set_lds(nerf_fwd_bf16_kernel<P>, BF16_LDS_BYTES)) return rc;
-    nerf_fwd_bf16_kernel<P><<<(unsigned)groups, Geo<P>::WG_THREADS, BF16_LDS_BYTES, (hipStream_t)stream>>>(a);
-    return nerf_check_launch(who);
+    if constexpr (P == 3) {
+        if (model == NERF_MODEL_SIREN) return launch_fwd<3, NERF_MODEL_SIREN>(a, M, stream, who);
+    }
+    return launch_fwd<P, NERF_MODEL_NERF>(a, M, stream, who);
+}
+
+}  // namespace
+
+#ifdef NERF_DIAG
+extern "C" void nerf_diag_bf16_stamps(unsigned long long* device_buffer) { g_bf16_dbg = device_buffer; }
+#endif
+
+extern "C" size_t nerf_mlp_packed_bf16_bytes(int model) { return model == NERF_MODEL_NERF ? Geo<1, NERF_MODEL_NERF>::PACKED_BYTES : 0; }
+extern "C" size_t nerf_mlp_packed_bf16x3_bytes(int model) {
+    return model == NERF_MODEL_NERF ? Geo<3, NERF_MODEL_NERF>::PACKED_BYTES
+         : model == NERF_MODEL_SIREN ? Geo<3, NERF_MODEL_SIREN>::PACKED_BYTES : 0;
+}
+
+extern "C" int nerf_mlp_pack_bf16(int model, const float* const* params, void* packed, void* stream) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_pack_bf16: the bf16 mode covers the NeRF model only (model %d)", model);
+    NERF_REQUIRE_PTR(params);
+    NERF_REQUIRE_PTR(packed);
+    return pack_image<1, NERF_MODEL_NERF>(params, packed, stream, "nerf_mlp_pack_bf16");
+}
+
+extern "C" int nerf_mlp_pack_bf16x3(int model, const float* const* params, void* packed, void* stream) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "nerf_mlp_pack_bf16x3: unknown model %d", model);
+    NERF_REQUIRE_PTR(params);
+    NERF_REQUIRE_PTR(packed);
+    return model == NERF_MODEL_NERF ? pack_image<3, NERF_MODEL_NERF>(params, packed, stream, "nerf_mlp_pack_bf16x3")
+                                    : pack_image<3, NERF_MODEL_SIREN>(params, packed, stream, "nerf_mlp_pack_bf16x3");
 }
 
 extern "C" int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const float* points, const float* dirs,

@@ -49,13 +49,13 @@ class _FusedMLP(nn.Module):
         (torch.no_grad() / parameters that do not require grad) on the bf16 matrix pipe.  'bf16': weights,
         encodings and activations are rounded to bf16 and accumulated in fp32 (tolerance of its own).
         'bf16x3': every fp32 operand is split into three bf16 terms and a product is formed from six term
-        products accumulated in fp32 -- fp32 accuracy (it holds the fp32 path's parity bar) at more than twice
-        the fp32 kernel's rate.  Training always runs fp32."""
+        products accumulated in fp32 -- fp32 accuracy (it holds the fp32 path's parity bar) at about 1.7 times
+        the fp32 kernel's rate; both models.  'bf16' covers NeRF only.  Training always runs fp32."""
         if precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'")
         if precision != "fp32":
             self._check_supported()
-            if _hip.lib.nerf_mlp_packed_bf16_bytes(self.model_id) == 0:
+            if getattr(_hip.lib, f"nerf_mlp_packed_{precision}_bytes")(self.model_id) == 0:
                 raise NotImplementedError(f"the {precision} inference mode covers the NeRF model only")
             if self._packed_bf16 is None or precision != self.inference_precision:
                 self._packed_bf16 = PackedWeights(self.model_id, _hip.mlp_pack_bf16 if precision == "bf16" else _hip.mlp_pack_bf16x3)

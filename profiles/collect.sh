@@ -30,7 +30,7 @@ pmc() {     # name, counters...
 modes() {
     : > "$OUT/${TAG}_bench_modes.jsonl"
     for args in "--sampling single" "--sampling single --model siren" "--model siren" "--mode infer" "--mode infer --sampling single" \
-                "--mode infer --precision bf16" "--mode infer --precision bf16 --rays 32768" "--mode infer --precision bf16x3" "--mode infer --precision bf16x3 --rays 32768" "--mode infer --precision bf16x3 --rays 640000 --steps 3 --warmup 1" "--mode infer --rays 640000 --steps 3 --warmup 1" \
+                "--mode infer --precision bf16" "--mode infer --precision bf16 --rays 32768" "--mode infer --precision bf16x3" "--mode infer --precision bf16x3 --rays 32768" "--mode infer --model siren" "--mode infer --model siren --precision bf16x3" "--mode infer --precision bf16x3 --rays 640000 --steps 3 --warmup 1" "--mode infer --rays 640000 --steps 3 --warmup 1" \
                 "--rays 1024" "--rays 16384"; do
         timeout -k 10 300 python3 bench.py $args --no-cpu-baseline >> "$OUT/${TAG}_bench_modes.jsonl" 2>> "$OUT/modes.err" || return 1
     done

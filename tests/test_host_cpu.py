@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_hip.lib, s), f"libnerf_hip.so does not export {s}"
         assert s in _hip.EXPORTS, f"{s} declared in nerf_hip.h but not bound in nerf/_hip.py"
-    assert _hip.lib.nerf_abi_version() == 8
+    assert _hip.lib.nerf_abi_version() == 9
 
 
 def test_sizes_match_reference_parameter_counts():
@@ -69,12 +69,14 @@ def test_argument_errors_of_the_optional_paths():
     assert lib.nerf_mlp_fwd_bf16(_hip.MODEL_NERF, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -2
     # three-term mode: three units per weight fragment, every layer starts a new 32 KiB chunk
     assert lib.nerf_mlp_packed_bf16x3_bytes(_hip.MODEL_NERF) == 124 * 32768 + 86 * 32 * 4
-    assert lib.nerf_mlp_packed_bf16x3_bytes(_hip.MODEL_SIREN) == 0
-    assert lib.nerf_mlp_fwd_bf16x3(_hip.MODEL_SIREN, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -1
-    assert b"NeRF model only" in lib.nerf_last_error()
+    assert lib.nerf_mlp_packed_bf16x3_bytes(_hip.MODEL_SIREN) == 107 * 32768 + 78 * 32 * 4      # both models
+    assert lib.nerf_mlp_packed_bf16x3_bytes(7) == 0
+    assert lib.nerf_mlp_fwd_bf16x3(7, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -1
+    assert lib.nerf_mlp_fwd_bf16x3(_hip.MODEL_SIREN, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -2
     assert lib.nerf_mlp_fwd_bf16x3(_hip.MODEL_NERF, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -2
     assert lib.nerf_mlp_fwd_bf16x3(_hip.MODEL_NERF, None, 0, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == 0
-    assert lib.nerf_mlp_pack_bf16x3(_hip.MODEL_SIREN, None, None, None) == -1
+    assert lib.nerf_mlp_pack_bf16x3(7, None, None, None) == -1
+    assert lib.nerf_mlp_pack_bf16x3(_hip.MODEL_SIREN, None, None, None) == -2
     assert lib.nerf_linear_fwd(None, 4, None, None, 10, 8, 3, 0, 1.0, 1.0, None, 3, None, None) == -1   # ldx < K
     assert lib.nerf_linear_fwd(None, 8, None, None, 10, 8, 3, 9, 1.0, 1.0, None, 3, None, None) == -1   # activation
     assert lib.nerf_linear_fwd(None, 8, None, None, 0, 8, 3, 0, 1.0, 1.0, None, 3, None, None) == 0     # empty batch
