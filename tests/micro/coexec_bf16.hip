@@ -62,7 +62,9 @@ __global__ __launch_bounds__(512, 1) void roles(float* out, int mfma_iters, int 
 
 // The three-term K loop in isolation: one wave per SIMD, every unit is one ds_read_b128 (issued PF units ahead) followed
 // by 3, 2 or 1 MFMAs on one accumulator (unit u of a fragment meets 3 - u terms of the other operand).
-template <int PF>
+// ORDER 0: read after the unit's MFMAs, scheduling barriers around them (the kernel's arrangement); 1: read in front of
+// the unit's MFMAs; 2: as 0 without scheduling barriers; 3: read after the first MFMA of the unit
+template <int PF, int ORDER = 0>
 __global__ __launch_bounds__(256, 1) void ldsfed(float* out, int iters) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -79,13 +81,24 @@ __global__ __launch_bounds__(256, 1) void ldsfed(float* out, int iters) {
         for (int u = 0; u < PF; ++u) a[u] = *reinterpret_cast<const bf16x8*>(buf + u * 1024);
 #pragma unroll
         for (int u = 0; u < 24; ++u) {
-            __builtin_amdgcn_sched_barrier(0);
+            if (ORDER != 2) __builtin_amdgcn_sched_barrier(0);
             const int t = (u / 3) & 7;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % PF], b0, acc[t], 0, 0, 0);
-            if (u % 3 < 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % PF], b1, acc[t], 0, 0, 0);
-            if (u % 3 < 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % PF], b2, acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (u + PF < 24) a[u % PF] = *reinterpret_cast<const bf16x8*>(buf + (u + PF) * 1024);
+            const bf16x8 au = a[u % PF];
+            if (ORDER == 1) {
+                if (u + PF < 24) a[u % PF] = *reinterpret_cast<const bf16x8*>(buf + (u + PF) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(au, b0, acc[t], 0, 0, 0);
+            if (ORDER == 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + PF < 24) a[u % PF] = *reinterpret_cast<const bf16x8*>(buf + (u + PF) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (u % 3 < 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(au, b1, acc[t], 0, 0, 0);
+            if (u % 3 < 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(au, b2, acc[t], 0, 0, 0);
+            if (ORDER != 2) __builtin_amdgcn_sched_barrier(0);
+            if (ORDER == 0 || ORDER == 2)
+                if (u + PF < 24) a[u % PF] = *reinterpret_cast<const bf16x8*>(buf + (u + PF) * 1024);
         }
     }
     float s = 0.f;
@@ -114,6 +127,9 @@ int main() {
     printf("K loop fed from LDS (3+2+1 MFMAs per unit): PF 2 %.3f ms, PF 4 %.3f ms, PF 8 %.3f ms\n",
            timed([&] { ldsfed<2><<<256, 256>>>(out, it); }), timed([&] { ldsfed<4><<<256, 256>>>(out, it); }),
            timed([&] { ldsfed<8><<<256, 256>>>(out, it); }));
+    printf("K loop fed from LDS, PF 4: read in front %.3f ms, no scheduling barriers %.3f ms, read after the first MFMA %.3f ms\n",
+           timed([&] { ldsfed<4, 1><<<256, 256>>>(out, it); }), timed([&] { ldsfed<4, 2><<<256, 256>>>(out, it); }),
+           timed([&] { ldsfed<4, 3><<<256, 256>>>(out, it); }));
     const int mi = 30000, vi = 10000;
     const float tm = timed([&] { roles<1><<<256, 512>>>(out, mi, vi, 1e-3f); });
     const float tv = timed([&] { roles<2><<<256, 512>>>(out, mi, vi, 1e-3f); });
