@@ -43,6 +43,7 @@ fi
 stats hier &&    # the default bench command itself (10 timed steps after 3 warm-ups)
 stats single --steps 6 --warmup 2 --sampling single &&
 stats siren --steps 6 --warmup 2 --sampling single --model siren &&
+stats infer_bf16x3 --steps 6 --warmup 2 --mode infer --precision bf16x3 --rays 32768 &&
 pmc fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
 pmc write WRITE_SIZE &&
 pmc sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
