@@ -15,12 +15,12 @@
 //
 // A wave owns 32 samples, a workgroup of 8 waves 256 samples.  All waves need the same weights in
 // the same order, so the packed image is streamed once per workgroup through a ring of four 32 KiB
-// LDS buffers with global_load_lds (no staging registers); one barrier per 32 KiB chunk both
+// LDS buffers with buffer_load ... lds (no staging registers); one barrier per 32 KiB chunk both
 // publishes chunk c and releases the buffer of chunk c-1 for chunk c+3.  The image is stored in
 // consumption order, one 1 KiB unit per MFMA: unit[lane][8 bf16] is read back with one
 // conflict-free ds_read_b128 per lane.
 //
-// Three-term variant (PLANES = 3, "bf16x3").  Every fp32 operand is written as the sum of three bf16 terms,
+// Three-term variant (template parameter P = 3, "bf16x3").  Every fp32 operand is written as the sum of three bf16 terms,
 // x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (the subtractions are exact), and a
 // product of two operands is formed from the six term products that reach fp32 precision:
 //     w*x ~= w0*x0 + w0*x1 + w0*x2 + w1*x0 + w1*x1 + w2*x0      (what is dropped is below 2^-24 of |w*x|)
