@@ -227,11 +227,14 @@ def bf16_round(x: Tensor) -> Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def nerf_forward_bf16(p: Params, points: Tensor, dirs: Tensor):
+def nerf_forward_bf16(p: Params, points: Tensor, dirs: Tensor, terms: int = 1):
     """The opt-in bf16 inference mode (no counterpart in the reference, which is fp32 throughout):
     nerf_forward with every weight and every layer input (encodings, activations) rounded to bf16,
-    products accumulated in higher precision (float64 here), biases / sigmoid / inputs in fp32."""
+    products accumulated in higher precision (float64 here), biases / sigmoid / inputs in fp32.
+    terms = 3: the three-term mode instead (linear_bf16x3), whose result is fp32-accurate."""
     def lin(x, name):
+        if terms == 3:
+            return linear_bf16x3(x, p[name + ".weight"], p[name + ".bias"])
         w = bf16_round(p[name + ".weight"]).double()
         return (bf16_round(x).double() @ w.t() + p[name + ".bias"].double()).float()
 
@@ -248,6 +251,28 @@ def nerf_forward_bf16(p: Params, points: Tensor, dirs: Tensor):
     g = torch.relu(lin(torch.cat([f[:, :-1], de], dim=1), "rgb_head.0"))
     colors = torch.sigmoid(lin(g, "rgb_head.2"))
     return colors, density
+
+
+def bf16_terms(x: Tensor, terms: int = 3):
+    """The three-term mode's expansion of fp32 values (no counterpart in the reference): x0 = bf16(x),
+    x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), every subtraction exact in fp32.  Returns the terms as fp32 tensors."""
+    out, r = [], x.to(torch.float32)
+    for _ in range(terms):
+        t = bf16_round(r)
+        out.append(t)
+        r = r - t
+    return out
+
+
+def linear_bf16x3(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """x @ w.T + b as the three-term kernels form it: the six term products w0x0, w0x1, w0x2, w1x0, w1x1, w2x0 (each
+    exact in fp32), accumulated here in float64 -- what remains relative to the exact product is the three dropped
+    term products, below 2^-24 of |w||x|."""
+    xs, ws = bf16_terms(x), bf16_terms(w)
+    acc = torch.zeros(x.shape[0], w.shape[0], dtype=torch.float64)
+    for i, j in ((0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (2, 0)):
+        acc += xs[j].double() @ ws[i].double().t()
+    return (acc + b.double()).float()
 
 
 def siren_forward(p: Params, points: Tensor, dirs: Tensor, num_layers: int = 8, dir_L: int = 4,

@@ -698,6 +698,9 @@ def test_bf16x3_inference_holds_fp32_bar(hip, M, tag):
         c, s = model(x.to(DEV), d.to(DEV))
     assert rel(c, c32) < RTOL, rel(c, c32)
     assert rel(s, s32) < RTOL, rel(s, s32)
+    if tag == "nerf":   # the oracle's restatement of the same six-product arithmetic (float64 accumulation): rounding-level
+        cx, sx = O.nerf_forward_bf16(params, x, d, terms=3)
+        assert rel(c, cx) < 2e-6 and rel(s, sx) < 2e-6, (rel(c, cx), rel(s, sx))
     # training never takes this kernel either
     c_train, _ = model(x.to(DEV), d.to(DEV))
     assert c_train.requires_grad and rel(c_train, c32) < RTOL

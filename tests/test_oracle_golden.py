@@ -204,3 +204,34 @@ def test_configuration_1_cpu_plumbing(tmp_path):
             O.adam_step(p, gr, torch.zeros_like(p), torch.zeros_like(p), 1, lr * factor)
     assert float(allp[0].detach().norm()) != before
     assert 0.0 < mse_to_psnr(float(torch.nn.functional.mse_loss(rf, tgt).detach())) < 60.0
+
+
+def test_three_term_expansion_properties():
+    """The arithmetic of the opt-in bf16x3 kernels, restated (no counterpart in the reference): the three bf16 terms of
+    an fp32 number reconstruct it exactly, every term product fits fp32, and a chain of layers formed from the six
+    products per product stays as close to a float64 evaluation as plain fp32 arithmetic does."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.cat([torch.randn(4096, generator=g) * s for s in (1e-6, 1e-2, 1.0, 37.0, 1e5)])
+    t0, t1, t2 = O.bf16_terms(x)
+    assert torch.equal((t0.double() + t1.double() + t2.double()).float(), x)          # exact, not merely close
+    assert torch.equal(t0 + t1 + t2, x)                                                # even summed in fp32
+    for t in (t0, t1, t2):
+        assert torch.equal(O.bf16_round(t), t)                                         # every term IS a bf16 number
+    assert float((t1.abs() / x.abs()).max()) <= 2.0 ** -8 and float((t2.abs() / x.abs()).max()) <= 2.0 ** -16
+    w = torch.randn(4096, generator=g)
+    for a in O.bf16_terms(w):
+        for b in (t0, t1, t2):
+            pr = a[:4096].double() * b[:4096].double()
+            assert torch.equal(pr.float().double(), pr)                                # 8 x 8 significant bits: exact in fp32
+    # an 8-layer 256-wide ReLU chain against float64
+    Ws = [torch.randn(256, 256, generator=g) * (2.0 / 256) ** 0.5 for _ in range(8)]
+    bs = [torch.randn(256, generator=g) * 0.1 for _ in range(8)]
+    h0 = torch.randn(512, 256, generator=g)
+    ref, f32, x3 = h0.double(), h0, h0
+    for W, b in zip(Ws, bs):
+        ref = torch.relu(ref @ W.double().t() + b.double())
+        f32 = torch.relu(f32 @ W.t() + b)
+        x3 = torch.relu(O.linear_bf16x3(x3, W, b))
+    e32 = float((f32.double() - ref).norm() / ref.norm())
+    e3 = float((x3.double() - ref).norm() / ref.norm())
+    assert e3 < 1e-6 and e3 <= 1.5 * e32, (e3, e32)
