@@ -314,8 +314,10 @@ def main():
                      ("mlp_fwd_infer_density", fl["density"], "the same pass stopped after the density row (coarse pass of a "
                                                            "hierarchical render; no feature layer, rgb layers or head)"),
                      ("mlp_fwd_infer_bf16", fl["fwd"], "bf16 opt-in: register-chain encode+MLP forward (inference)"),
+                     ("mlp_fwd_infer_bf16_density", fl["density"], "bf16 opt-in, stopped after the density row"),
                      ("mlp_fwd_infer_bf16x3", 6 * fl["fwd"], "bf16x3 opt-in: the same chain with every fp32 operand as three bf16 terms; "
-                                                             "matrix-pipe flops = 6 term products per product of the fp32 algorithm")]
+                                                             "matrix-pipe flops = 6 term products per product of the fp32 algorithm"),
+                     ("mlp_fwd_infer_bf16x3_density", 6 * fl["density"], "bf16x3 opt-in, stopped after the density row")]
         table = {}
         for base, flop_per_sample, desc in specs:
             for name in (base, base + "@side"):
@@ -383,7 +385,7 @@ def main():
             "metric": (f"train rays/sec (fwd+bwd+Adam, {args.coarse}+{args.fine} samples/ray)" if hier else
                        f"train rays/sec (fwd+bwd+Adam, {S} samples/ray single pass)") if args.mode == "train"
                       else (f"inference rays/sec ({S} MLP evaluations/ray"
-                            + (f", the {args.coarse} coarse ones density only)" if hier and args.precision == "fp32" else ")")),
+                            + (f", the {args.coarse} coarse ones density only)" if hier else ")")),
             "value": world * B * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3 (three bf16 terms per fp32 operand, fp32 accumulate)"}[args.precision], "data": "synthetic",

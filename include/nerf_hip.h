@@ -137,7 +137,8 @@ int nerf_mlp_fwd(int model, const float* packed, int64_t M, const float* points,
  * biases, the sigmoid and the sample positions stay fp32.  Not a parity path: expect about 1e-2
  * absolute deviation of colors from the fp32 kernels.  `packed` is an image of
  * nerf_mlp_packed_bf16_bytes(model) BYTES built by nerf_mlp_pack_bf16 (re-run after every
- * parameter change); it is unrelated to the fp32 image of nerf_mlp_pack. */
+ * parameter change); it is unrelated to the fp32 image of nerf_mlp_pack.  colors == NULL: the pass stops after the
+ * layer that holds the density row and writes densities only (as nerf_mlp_fwd does). */
 size_t nerf_mlp_packed_bf16_bytes(int model);                  /* 0 for models without a bf16 kernel */
 int nerf_mlp_pack_bf16(int model, const float* const* params, void* packed, void* stream);
 int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const float* points, const float* dirs,

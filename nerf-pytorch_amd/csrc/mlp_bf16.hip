@@ -312,7 +312,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // meets the terms 0..2-p of the B fragment (3 + 2 + 1 MFMAs per fragment, consecutive ones on one accumulator
 // run at full rate).
 // TAIL = chunks that follow this layer's last chunk in the whole stream (2 = two or more).
-template <int P, int NOT, int NKS_A, int NKS_E, int TAIL>
+// FIRST_OT: output tiles below it are not computed (the density-only pass needs the ninth tile of its last layer alone).
+template <int P, int NOT, int NKS_A, int NKS_E, int TAIL, int FIRST_OT = 0>
 __device__ __forceinline__ void mma_layer16(Ring& r, int lane, f32x16 (&acc)[9], const bf16x8 (&XA)[P][16],
                                             const bf16x8 (&XE)[P][4]) {
     constexpr int NKS = NKS_A + NKS_E, UNITS = P * NOT * NKS, CHUNKS = (UNITS + CHUNK_UNITS - 1) / CHUNK_UNITS;
@@ -342,13 +343,14 @@ __device__ __forceinline__ void mma_layer16(Ring& r, int lane, f32x16 (&acc)[9],
     static_for<UNITS>([&](auto U) {
         constexpr int u = decltype(U)::value, p = u % P, ks = (u / P) / NOT, ot = (u / P) % NOT;
         __builtin_amdgcn_sched_barrier(0);
-        static_for<P - p>([&](auto Q) {
-            constexpr int q = decltype(Q)::value;
-            bf16x8 b;
-            if constexpr (ks < NKS_A) b = XA[q][ks];
-            else b = XE[q][ks - NKS_A];
-            acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % PF], b, acc[ot], 0, 0, 0);
-        });
+        if constexpr (ot >= FIRST_OT)      // (FIRST_OT > 0: the units of the skipped tiles still pass through the ring)
+            static_for<P - p>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                bf16x8 b;
+                if constexpr (ks < NKS_A) b = XA[q][ks];
+                else b = XE[q][ks - NKS_A];
+                acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % PF], b, acc[ot], 0, 0, 0);
+            });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (u + PF < UNITS) fetch(std::integral_constant<int, u + PF>{});
     });
@@ -460,7 +462,9 @@ __device__ __forceinline__ float norm_coord16(float p, float nearf, float spanf)
     return sub_rn(div_rn(mul_rn(2.0f, sub_rn(p, nearf)), spanf), 1.0f);
 }
 
-template <int P, int MODEL>
+// DENSITY_ONLY (colors == NULL): the stream ends with the layer that holds the density row -- the coarse pass of a
+// hierarchical render without gradients feeds only the re-sampling.
+template <int P, int MODEL, bool DENSITY_ONLY = false>
 __global__ __launch_bounds__(wg_threads(P), 1) void fwd_bf16_kernel(Bf16Args a) {
     using G = Geo<P, MODEL>;
     constexpr int WG_THREADS = G::WG_THREADS, WG_SAMPLES = G::WG_SAMPLES, PER_CHUNK = G::PER_CHUNK;
@@ -501,7 +505,10 @@ __global__ __launch_bounds__(wg_threads(P), 1) void fwd_bf16_kernel(Bf16Args a) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing ordinary is outstanding from here on
     __builtin_amdgcn_sched_barrier(0);
-    Ring ring{a.img, smem, 0, 16u * (unsigned)tid, wave, G::NCHUNK, (int)G::IMG_BYTES, PER_CHUNK, WG_THREADS};
+    constexpr int DENSITY_LAYER = MODEL == NERF_MODEL_NERF ? 9 : 8;
+    // chunks of the stream this variant reads (nothing may be in flight towards LDS when the workgroup ends)
+    constexpr int NCHUNK_RUN = DENSITY_ONLY ? G::chunk0(DENSITY_LAYER + 1) : G::NCHUNK;
+    Ring ring{a.img, smem, 0, 16u * (unsigned)tid, wave, NCHUNK_RUN, (int)G::IMG_BYTES, PER_CHUNK, WG_THREADS};
     ring_issue(ring, 0);   // these land while the encodings below are computed
     ring_issue(ring, 1);
     ring_issue(ring, 2);
@@ -591,6 +598,11 @@ __global__ __launch_bounds__(wg_threads(P), 1) void fwd_bf16_kernel(Bf16Args a) 
         }
         // block2.8: 256 feature rows (no activation) + the density row (first row of the ninth tile)
         init_bias<9>(acc, bias_lds, bias_tile0(9), h);
+        if constexpr (DENSITY_ONLY) {
+            mma_layer16<P, 9, 16, 0, 0, 8>(ring, lane, acc, X, E0);
+            if (valid && h == 0) a.density[m] = fmaxf(acc[8][0], 0.0f);
+            return;
+        }
         mma_layer16<P, 9, 16, 0, 2>(ring, lane, acc, X, E0);
         dens = fmaxf(acc[8][0], 0.0f);
         to_frags<P, 8, FR_NONE>(acc, X);
@@ -617,6 +629,11 @@ __global__ __launch_bounds__(wg_threads(P), 1) void fwd_bf16_kernel(Bf16Args a) 
         }
         DIAG_STAMP(3);
         init_bias<9>(acc, bias_lds, bias_tile0(8), h);
+        if constexpr (DENSITY_ONLY) {
+            mma_layer16<P, 9, 16, 0, 0, 8>(ring, lane, acc, X, E0);
+            if (valid && h == 0) a.density[m] = fmaxf(acc[8][0], 0.0f) * 10.0f;
+            return;
+        }
         mma_layer16<P, 9, 16, 0, 2>(ring, lane, acc, X, E0);
         dens = fmaxf(acc[8][0], 0.0f) * 10.0f;           // relu(sigma) * sigma_mul (models.py:193)
         to_frags<P, 8, FR_NONE>(acc, X);
@@ -661,8 +678,13 @@ template <int P, int MODEL>
 int launch_fwd(const Bf16Args& a, int64_t M, void* stream, const char* who) {
     const int64_t groups = ceil_div64(M, Geo<P, MODEL>::WG_SAMPLES);
     if (groups >= (1ll << 31)) return nerf_fail(NERF_E_ARG, "%s: too many samples", who);
-    if (int rc = nerf_set_lds(fwd_bf16_kernel<P, MODEL>, BF16_LDS_BYTES)) return rc;
-    fwd_bf16_kernel<P, MODEL><<<(unsigned)groups, wg_threads(P), BF16_LDS_BYTES, (hipStream_t)stream>>>(a);
+    if (a.colors) {
+        if (int rc = nerf_set_lds(fwd_bf16_kernel<P, MODEL, false>, BF16_LDS_BYTES)) return rc;
+        fwd_bf16_kernel<P, MODEL, false><<<(unsigned)groups, wg_threads(P), BF16_LDS_BYTES, (hipStream_t)stream>>>(a);
+    } else {
+        if (int rc = nerf_set_lds(fwd_bf16_kernel<P, MODEL, true>, BF16_LDS_BYTES)) return rc;
+        fwd_bf16_kernel<P, MODEL, true><<<(unsigned)groups, wg_threads(P), BF16_LDS_BYTES, (hipStream_t)stream>>>(a);
+    }
     return nerf_check_launch(who);
 }
 
@@ -679,7 +701,7 @@ int fwd_terms(const char* who, int model, const void* packed, int64_t M, const f
         return nerf_fail(NERF_E_ARG, P == 1 ? "%s: the bf16 mode covers the NeRF model only (model %d)" : "%s: unknown model %d", who, model);
     if (M < 0) return nerf_fail(NERF_E_ARG, "%s: M=%lld < 0", who, (long long)M);
     if (M == 0) return NERF_OK;
-    if (!packed || !colors || !density) return nerf_fail(NERF_E_NULL, "%s: packed, colors and density must not be NULL", who);
+    if (!packed || !density) return nerf_fail(NERF_E_NULL, "%s: packed and density must not be NULL", who);
     if (points) {
         if (!dirs) return nerf_fail(NERF_E_NULL, "%s: dirs is NULL", who);
     } else {

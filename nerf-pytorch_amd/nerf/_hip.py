@@ -311,8 +311,9 @@ def mlp_pack_bf16x3(model: int, params: Sequence[torch.Tensor], out: Optional[to
 
 
 def mlp_fwd_bf16(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None, rays_o=None, rays_d=None, t=None,
-                 S: int = 0, near: float = 0.0, far: float = 1.0):
-    """Inference forward on the bf16 matrix pipe; the image's size says which of the two modes it was packed for."""
+                 S: int = 0, near: float = 0.0, far: float = 1.0, want_colors: bool = True):
+    """Inference forward on the bf16 matrix pipe; the image's size says which of the two modes it was packed for.
+    want_colors=False: the pass stops after the layer that holds the density row; colors come back as None."""
     dev = packed.device
     if packed.numel() == lib.nerf_mlp_packed_bf16_bytes(model):
         name = "bf16"
@@ -320,13 +321,13 @@ def mlp_fwd_bf16(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=
         name = "bf16x3"
     else:
         raise ValueError(f"packed image of {packed.numel()} bytes is neither a bf16 nor a bf16x3 image of model {model}")
-    colors = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    colors = torch.empty((M, 3), dtype=torch.float32, device=dev) if want_colors else None
     density = torch.empty((M,), dtype=torch.float32, device=dev)
-    ev = timers.start(f"mlp_fwd_infer_{name}", M)
+    ev = timers.start(f"mlp_fwd_infer_{name}" + ("" if want_colors else "_density"), M)
     _check(getattr(lib, f"nerf_mlp_fwd_{name}")(model, _dev(packed, "packed", torch.uint8), M, _opt(points, "points"),
                                                _opt(dirs, "dirs"), _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S,
                                                int(t is not None and t.dim() == 2), float(near), float(far),
-                                               _dev(colors, "colors"), _dev(density, "density"), _stream()), f"nerf_mlp_fwd_{name}")
+                                               _opt(colors, "colors"), _dev(density, "density"), _stream()), f"nerf_mlp_fwd_{name}")
     timers.stop(ev)
     return colors, density, None
 

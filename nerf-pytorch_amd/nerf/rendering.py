@@ -179,8 +179,7 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
     wc, wf = coarse.packed_weights(tc_train), fine.packed_weights(tf_train)
     sink_c = grad_sink(coarse, pc) if tc_train else None
     sink_f = grad_sink(fine, pf) if tf_train else None
-    density_only = (not coarse_rgb and not tc_train and not tf_train
-                    and wc.dtype == torch.float32)     # (a bf16 image is uint8: that kernel has no shortened variant)
+    density_only = not coarse_rgb and not tc_train and not tf_train
     out_c, out_f, extras = [], [], []
     for ci, i in enumerate(range(0, rays_o.shape[0], chunk_size)):
         o, d = rays_o[i:i + chunk_size], rays_d[i:i + chunk_size]
@@ -201,8 +200,9 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
             w_c.record_stream(main)
         elif density_only:
             # no gradients, no coarse image: densities from the shortened pass, compositing weights only
-            _, dens_c, _ = _hip.mlp_fwd(coarse.model_id, wc, R * num_coarse, rays_o=o, rays_d=d, t=t_c, S=num_coarse,
-                                        near=near, far=far, want_colors=False)
+            fwd = _hip.mlp_fwd_bf16 if wc.dtype == torch.uint8 else _hip.mlp_fwd     # (a bf16 / bf16x3 image is uint8)
+            _, dens_c, _ = fwd(coarse.model_id, wc, R * num_coarse, rays_o=o, rays_d=d, t=t_c, S=num_coarse,
+                               near=near, far=far, want_colors=False)
             rgb_c = None
             w_c = _hip.composite_fwd(None, dens_c.view(R, num_coarse), deltas_c, bool(white_background))[1]
         else:

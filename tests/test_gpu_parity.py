@@ -731,6 +731,17 @@ def test_bf16x3_render_matches_fp32_render(hip, tag):
     # the fine depths are drawn from the coarse weights: on a handful of rays an fp32-rounding difference there is
     # amplified by the re-sampling (measured: 3 / 8 of 2048 rays beyond 1e-5, max 3e-5 / 1.5e-4 for NeRF / Siren), as
     # between any two fp32 implementations; the image as a whole stays inside the parity bar
+    # the coarse pass stopped at the densities (what eval.py asks for): the same densities bit for bit, so the same fine image
+    with torch.no_grad():
+        torch.manual_seed(5)
+        short = render_nerf_hierarchical(model, fine, o, d, 2.0, 6.0, 64, 128, device=DEV, coarse_rgb=False)
+        pts = torch.rand(1000, 3, device=DEV) * 2 - 1
+        dd = torch.nn.functional.normalize(torch.randn(1000, 3, device=DEV), dim=1)
+        img = model.packed_weights(False)
+        full_c, full_s, _ = hip.mlp_fwd_bf16(model.model_id, img, 1000, points=pts, dirs=dd)
+        none_c, only_s, _ = hip.mlp_fwd_bf16(model.model_id, img, 1000, points=pts, dirs=dd, want_colors=False)
+    assert short[0] is None and torch.equal(short[1], out_h[1])
+    assert none_c is None and torch.equal(only_s, full_s)
     err = (out_h[1] - ref_h[1]).abs().max(dim=1)[0]
     assert rel(out_h[1], ref_h[1]) < RTOL, rel(out_h[1], ref_h[1])
     assert float(err.max()) < 1e-3 and int((err > 1e-5).sum()) <= R // 100, (float(err.max()), int((err > 1e-5).sum()))
