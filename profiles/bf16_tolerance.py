@@ -1,6 +1,7 @@
-"""Tolerance-versus-fp32 report of the opt-in bf16 inference mode at the large-batch stress shape:
-262,144 rays x 256 MLP evaluations per ray, same rays and same stratified draws in both precisions.
-Run on the GPU box:  python profiles/bf16_tolerance.py > profiles/r1_bf16_tolerance.json"""
+"""Tolerance-versus-fp32 report of the opt-in inference modes (bf16: one term per operand; bf16x3: three terms,
+fp32 accuracy) at the large-batch stress shape: 262,144 rays x 256 MLP evaluations per ray, same rays and same
+stratified draws in every precision.
+Run on the GPU box:  python profiles/bf16_tolerance.py > profiles/r2_bf16_tolerance.json"""
 import json, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nerf-pytorch_amd"))
@@ -58,8 +59,10 @@ with torch.no_grad():
         single = lambda: render_nerf(model, o, d, 2.0, 6.0, num_samples=S, device=DEV, chunk_size=CHUNK, u=u)
         model.set_inference_precision("fp32"); ref, t32 = timed(single)
         model.set_inference_precision("bf16"); out, t16 = timed(single)
+        model.set_inference_precision("bf16x3"); out3, t3 = timed(single)
         case = {"weights": f"default init x {gain}, density bias + {DENSITY_BIAS}, seed {seed}", "sampling": "single pass, 256 stratified samples",
-                "fp32_rays_per_s": R / t32, "bf16_rays_per_s": R / t16, **stats(out, ref)}
+                "fp32_rays_per_s": R / t32, "bf16_rays_per_s": R / t16, "bf16x3_rays_per_s": R / t3, **stats(out, ref),
+                "bf16x3": stats(out3, ref)}
         report["cases"].append(case)
         print(json.dumps(case), file=sys.stderr, flush=True)
     torch.manual_seed(10)
@@ -71,8 +74,10 @@ with torch.no_grad():
     ref, t32 = timed(hier)
     for m in (coarse, fine): m.set_inference_precision("bf16")
     out, t16 = timed(hier)
+    for m in (coarse, fine): m.set_inference_precision("bf16x3")
+    out3, t3 = timed(hier)
     case = {"weights": f"default init x {HIER_GAIN}, density bias + {DENSITY_BIAS}, seed 10 (coarse + fine)", "sampling": "64 coarse + 192 importance samples, fine pass over the merged 256",
-            "fp32_rays_per_s": R / t32, "bf16_rays_per_s": R / t16, **stats(out, ref),
+            "fp32_rays_per_s": R / t32, "bf16_rays_per_s": R / t16, "bf16x3_rays_per_s": R / t3, **stats(out, ref), "bf16x3": stats(out3, ref),
             "note": "the fine sample positions follow the coarse weights, which differ between the precisions"}
     report["cases"].append(case)
 print(json.dumps(report, indent=1))
