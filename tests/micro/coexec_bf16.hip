@@ -106,6 +106,41 @@ __global__ __launch_bounds__(256, 1) void ldsfed(float* out, int iters) {
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// The same loop on 16-sample tiles (v_mfma_f32_16x16x32_bf16, 4 passes): 64 + 96 registers instead of 128 + 192, so two
+// waves fit a SIMD -- but every 1 KiB unit then feeds 16 samples instead of 32: with 8 waves per CU the LDS must deliver
+// 128 bytes per cycle, its peak.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int PF>
+__global__ __launch_bounds__(512, 1) void ldsfed16(float* out, int iters) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[32768];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 32768 / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = 0x3c003c00u + i;
+    __syncthreads();
+    f32x4 acc[16];
+    for (int t = 0; t < 16; ++t) for (int g = 0; g < 4; ++g) acc[t][g] = 0.f;
+    const u32x4 w = {0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u};
+    const bf16x8 b0 = __builtin_bit_cast(bf16x8, w), b1 = b0, b2 = b0;
+    const unsigned char* buf = smem + 16 * lane;
+    bf16x8 a[PF];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) a[u] = *reinterpret_cast<const bf16x8*>(buf + u * 1024);
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int t = (u / 3) & 15;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u % PF], b0, acc[t], 0, 0, 0);
+            if (u % 3 < 2) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u % PF], b1, acc[t], 0, 0, 0);
+            if (u % 3 < 1) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u % PF], b2, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + PF < 24) a[u % PF] = *reinterpret_cast<const bf16x8*>(buf + (u + PF) * 1024);
+        }
+    }
+    float s = 0.f;
+    for (int t = 0; t < 16; ++t) for (int g = 0; g < 4; ++g) s += acc[t][g];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
 template <typename F>
 float timed(F launch) {
     hipEvent_t e0, e1;
@@ -130,6 +165,9 @@ int main() {
     printf("K loop fed from LDS, PF 4: read in front %.3f ms, no scheduling barriers %.3f ms, read after the first MFMA %.3f ms\n",
            timed([&] { ldsfed<4, 1><<<256, 256>>>(out, it); }), timed([&] { ldsfed<4, 2><<<256, 256>>>(out, it); }),
            timed([&] { ldsfed<4, 3><<<256, 256>>>(out, it); }));
+    // 8 waves x 480,000 MFMAs of 16 cycles: the same matrix-pipe time per SIMD as the 4-wave loops above (6.4 ms at 2.4 GHz)
+    printf("16-sample tiles, two waves per SIMD, K loop fed from LDS: PF 4 %.3f ms, PF 8 %.3f ms\n",
+           timed([&] { ldsfed16<4><<<256, 512>>>(out, it); }), timed([&] { ldsfed16<8><<<256, 512>>>(out, it); }));
     const int mi = 30000, vi = 10000;
     const float tm = timed([&] { roles<1><<<256, 512>>>(out, mi, vi, 1e-3f); });
     const float tv = timed([&] { roles<2><<<256, 512>>>(out, mi, vi, 1e-3f); });
