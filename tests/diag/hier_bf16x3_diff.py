@@ -1,5 +1,11 @@
-import sys, os
-sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/nerf-pytorch_amd"); sys.path.insert(0, "/root/repo")
+"""Hierarchical renders of the fp32 kernels and of the three-term mode on the same rays and draws: how far do the fine
+images differ when only the coarse pass / both passes change precision?  (The re-sampling amplifies rounding-level
+differences of the coarse weights on a few rays.)"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for sub in ("tests", "nerf-pytorch_amd", ""):
+    sys.path.insert(0, os.path.join(ROOT, sub))
 import torch
 import test_gpu_parity as T
 from nerf.rendering import render_nerf_hierarchical
