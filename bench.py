@@ -388,7 +388,7 @@ def main():
                             + (f", the {args.coarse} coarse ones density only)" if hier else ")")),
             "value": world * B * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3 (three bf16 terms per fp32 operand, fp32 accumulate)"}[args.precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
             "config": {"workload": f"lego-shaped synthetic {args.res}x{args.res} scene, {B} rays/GPU/step, "
                                    + (f"{args.coarse} coarse + ({args.coarse}+{args.fine}) fine = {S} MLP evaluations/ray, "
                                       f"coarse+fine {args.model} MLPs" if hier else
