@@ -204,25 +204,32 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
     // 32-bit lane offset never changes -- no vector instructions per chunk (they would cost matrix-pipe time).
     const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.dY + (size_t)c0 * 32 * a.ldy, (unsigned)((size_t)(c1 - c0) * 32 * a.ldy * 4));
     const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(a.X + (size_t)c0 * 32 * a.ldx, (unsigned)((size_t)(c1 - c0) * 32 * a.ldx * 4));
-    auto stage_part = [&](__amdgpu_buffer_rsrc_t rsrc, int chunk_rel, int ld, auto width, float* dst) {
+    // piece i of a part: 512 consecutive 16-byte pieces, one per thread
+    auto stage_piece = [&](__amdgpu_buffer_rsrc_t rsrc, int chunk_rel, int ld, auto width, float* dst, int i) {
         constexpr int W4 = decltype(width)::value / 4, TOT = 32 * W4;  // TOT is a multiple of 64
         const int soff = chunk_rel * 32 * ld * 4;
-#pragma unroll
-        for (int i = 0; i < (TOT + 511) / 512; ++i) {
-            const int v = tid + i * 512;
-            const int voff = ((v / W4) * ld + 4 * (v % W4)) * 4;
-            if (v < TOT)  // whole waves are in or out
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 4 * (64 * wave + i * 512)),
-                                                     16, voff, soff, 0, 0);
-        }
+        const int v = tid + i * 512;
+        const int voff = ((v / W4) * ld + 4 * (v % W4)) * 4;
+        if (v < TOT)  // whole waves are in or out
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 4 * (64 * wave + i * 512)),
+                                                 16, voff, soff, 0, 0);
     };
-    auto stage = [&](int chunk, float* buf) {
-        stage_part(y_rsrc, chunk - c0, a.ldy, std::integral_constant<int, NW>{}, buf);
-        stage_part(x_rsrc, chunk - c0, a.ldx, std::integral_constant<int, KW>{}, buf + 32 * NW);
-        if (RANK1 && tid < 32)
+    constexpr int YPIECES = (32 * NW / 4 + 511) / 512, XPIECES = (32 * KW / 4 + 511) / 512, NPIECES = YPIECES + XPIECES + (RANK1 ? 1 : 0);
+    // One of the NPIECES LDS-DMA instructions of a thread for the next chunk.  An LDS-DMA instruction holds the issuing wave
+    // for some tens of cycles, and all waves of the workgroup reach this point together: issued in a row at the top of a
+    // chunk they leave the matrix pipe idle, one per MFMA block they disappear behind the MFMAs.
+    auto stage_one = [&](int chunk, float* buf, int i) {
+        if (i < YPIECES) stage_piece(y_rsrc, chunk - c0, a.ldy, std::integral_constant<int, NW>{}, buf, i);
+        else if (i < YPIECES + XPIECES) stage_piece(x_rsrc, chunk - c0, a.ldx, std::integral_constant<int, KW>{}, buf + 32 * NW, i - YPIECES);
+        else if (RANK1 && tid < 32)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.q + (size_t)chunk * 32 + tid),
                                              (__attribute__((address_space(3))) void*)(buf + 32 * ROWF), 4, 0, 0);
     };
+    auto stage = [&](int chunk, float* buf) {
+#pragma unroll
+        for (int i = 0; i < NPIECES; ++i) stage_one(chunk, buf, i);
+    };
+    static_assert(NPIECES <= 16, "one piece per MFMA block of a chunk");
     // bias column sums: all 512 threads take part, thread (grp, c4) adds rows grp*BROWS.. of the four
     // columns 4*c4.. (16-byte LDS reads: a quarter of the LDS instructions of a column-per-thread split)
     constexpr int BGRP = 512 / (NW / 4), BROWS = 32 / BGRP;
@@ -240,7 +247,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
     for (int c = c0; c < c1; ++c) {
         const float* buf = smem + ((c - c0) & 1) * BUF;
         float* nbuf = smem + (((c - c0) & 1) ^ 1) * BUF;
-        if (c + 1 < c1) stage(c + 1, nbuf);  // nbuf was last read before the previous barrier
+        const bool more = c + 1 < c1;        // nbuf was last read before the previous barrier
+        if (more && !active) stage(c + 1, nbuf);   // (waves without a tile have no MFMA blocks to hide the pieces behind)
         if (active) {
             // Tile i of this wave covers output rows n0 + TN*rho + i (rho = the MFMA row index) and tile j
             // columns k0 + TK*col + j: a lane's TN A values and TK B values of a sample are then adjacent
@@ -277,10 +285,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int s = 0; s < 16; s += 2) {
                 lds_frags(s + 1, av1, bv1);
+                if (s < NPIECES && more) stage_one(c + 1, nbuf, s);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(av0, bv0);
                 __builtin_amdgcn_sched_barrier(0);
                 lds_frags(s + 2 < 16 ? s + 2 : 15, av0, bv0);
+                if (s + 1 < NPIECES && more) stage_one(c + 1, nbuf, s + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(av1, bv1);
                 __builtin_amdgcn_sched_barrier(0);
