@@ -41,44 +41,62 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (without sparsity)
 PEAK_HBM_GBS = 8000.0
 PROFILES = os.path.join(ROOT, "profiles")
-# kernel-name fragments of the timed launches in the rocprofv3 counter summaries
-PMC_KERNEL = {("nerf", "mlp_fwd_train"): "nerf_fwd_kernel<true>", ("nerf", "mlp_bwd_data"): "nerf_dgrad_kernel",
-              ("nerf", "mlp_fwd_infer"): "nerf_fwd_kernel<false>", ("siren", "mlp_fwd_train"): "siren_fwd_kernel<true>",
-              ("siren", "mlp_bwd_data"): "siren_dgrad_kernel", ("siren", "mlp_fwd_infer"): "siren_fwd_kernel<false>"}
+# (function name, leading template arguments) of the timed launches as profiles/kernel_names.py keys them; trailing
+# template parameters a kernel may gain later do not break the match
+PMC_KERNEL = {("nerf", "mlp_fwd_train"): ("nerf_fwd_kernel", ("true",)), ("nerf", "mlp_bwd_data"): ("nerf_dgrad_kernel", ()),
+              ("nerf", "mlp_fwd_infer"): ("nerf_fwd_kernel", ("false", "false")),
+              ("siren", "mlp_fwd_train"): ("siren_fwd_kernel", ("true",)), ("siren", "mlp_bwd_data"): ("siren_dgrad_kernel", ()),
+              ("siren", "mlp_fwd_infer"): ("siren_fwd_kernel", ("false", "false"))}
+# HBM bytes per MLP evaluation the kernels move BY DESIGN (csrc/mlp_layout.h): the forward writes its workspace
+# (2857 / 4517 floats per sample) and reads 24 B of ray data per 256 samples; the data gradient writes every layer's
+# dY (2693 / 2437 floats) and reads the head's inputs, the ReLU mask words or the stored cosines.  The packed
+# weights (5 MB) stay in the caches.
+DESIGN_BYTES = {("nerf", "mlp_fwd_train"): 4 * 2857, ("nerf", "mlp_bwd_data"): 4 * (2693 + 128 + 72 + 8),
+                ("siren", "mlp_fwd_train"): 4 * 4517, ("siren", "mlp_bwd_data"): 4 * (2437 + 8 * 256 + 256 + 8)}
 
 
-def pmc_traffic_per_sample(model, kernel):
+def pmc_traffic_per_sample(model, kernel, profiles=None):
     """HBM bytes per MLP evaluation of one kernel from the newest committed `rocprofv3 --pmc` passes
-    (profiles/r<N>_pmc_fetch.csv, r<N>_pmc_write.csv: profiles/summarize_pmc.py output, KiB per dispatch;
+    (profiles/r<N>_pmc[_siren]_fetch.csv, ..._write.csv: profiles/summarize_pmc.py output, KiB per dispatch;
     r<N>_pmc_meta.json names the samples per dispatch of that profiled command).  FETCH_SIZE is doubled:
     on gfx950 it reports half the bytes of wide coalesced reads.  Counters cannot be read from inside
-    this process; the figure is per sample of the profiled build, so it is None when no pass is found."""
+    this process; the figure is per sample of the profiled build.  (None, None) when no pass covers the kernel --
+    with a line on stderr when counter files exist but hold no row for it, so that a renamed kernel cannot
+    silently empty roofline.traffic."""
     import csv
     import glob
     import re
-    frag = PMC_KERNEL.get((model, kernel))
-    metas = sorted(glob.glob(os.path.join(PROFILES, "r*_pmc_meta.json")),
-                   key=lambda f: int(re.search(r"r(\d+)_pmc_meta", f).group(1)))
-    if frag is None or not metas:
+    profiles = profiles or PROFILES
+    if profiles not in sys.path:
+        sys.path.insert(0, profiles)
+    from kernel_names import matches
+    want = PMC_KERNEL.get((model, kernel))
+    if want is None:
         return None, None
-    with open(metas[-1]) as f:
-        meta = json.load(f)
-    tag = os.path.basename(metas[-1]).split("_pmc_meta")[0]
-    kib = {}
-    files = []
-    for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        path = os.path.join(PROFILES, f"{tag}_pmc_{which}.csv")
-        if not os.path.exists(path):
+    infix = "" if model == "nerf" else f"_{model}"
+    metas = sorted(glob.glob(os.path.join(profiles, "r*_pmc_meta.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_pmc_meta", f).group(1)), reverse=True)
+    for meta_path in metas:       # newest round that profiled this model
+        tag = os.path.basename(meta_path).split("_pmc_meta")[0]
+        paths = [os.path.join(profiles, f"{tag}_pmc{infix}_{which}.csv") for which in ("fetch", "write")]
+        if not all(os.path.exists(p) for p in paths):
+            continue
+        with open(meta_path) as f:
+            meta = json.load(f)
+        kib = {}
+        for path, counter in zip(paths, ("FETCH_SIZE", "WRITE_SIZE")):
+            with open(path, newline="") as f:
+                for row in csv.DictReader(f):
+                    if row["counter"] == counter and matches(row.get("kernel_key") or row["kernel"], *want):
+                        kib[counter] = float(row["mean_per_dispatch"])
+        if len(kib) != 2:
+            print(f"bench.py: {[os.path.basename(p) for p in paths]} hold no FETCH_SIZE/WRITE_SIZE row for "
+                  f"{want[0]}<{','.join(want[1])}...>: roofline.traffic left empty", file=sys.stderr)
             return None, None
-        files.append(os.path.relpath(path, ROOT))
-        with open(path, newline="") as f:
-            for row in csv.DictReader(f):
-                if frag in row["kernel"] and row["counter"] == counter:
-                    kib[counter] = float(row["mean_per_dispatch"])
-    if len(kib) != 2:
-        return None, None
-    per_sample = (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0 / float(meta["samples_per_dispatch"])
-    return per_sample, files + [os.path.relpath(metas[-1], ROOT)]
+        per_sample = (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0 / float(meta["samples_per_dispatch"])
+        root = os.path.dirname(os.path.abspath(profiles))
+        return per_sample, [os.path.relpath(p, root) for p in paths + [meta_path]]
+    return None, None
 
 
 def make_rays(n_views, H, W, device, seed=42):

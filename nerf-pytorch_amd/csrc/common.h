@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <mutex>
+
 #include "../../include/nerf_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -37,26 +39,29 @@ static inline int nerf_check_launch(const char* what) {
     return NERF_OK;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel that never changes once
-// set: raise it on the first launch of `kernel` on each device and skip the runtime call afterwards.
-// (A concurrent first call from two threads sets the same value twice, which is harmless.)
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: raise it when `kernel` first
+// runs on a device, or when a launch needs more than every earlier one asked for (a kernel whose LDS size
+// depends on its arguments), and skip the runtime call otherwise.  The table of (kernel, device) -> largest size
+// set so far is shared by all host threads and guarded by a mutex.
 template <typename K>
 static inline int nerf_set_lds(K kernel, int bytes) {
-    constexpr int kSlots = 32, kDevs = 16;
+    constexpr int kSlots = 64, kDevs = 16;
+    static std::mutex mu;
     static const void* known[kSlots] = {};
-    static unsigned char done[kSlots][kDevs] = {};
+    static int set_bytes[kSlots][kDevs] = {};
     const void* fn = reinterpret_cast<const void*>(kernel);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs) dev = -1;
+    std::lock_guard<std::mutex> lock(mu);
     int slot = -1;
     for (int i = 0; i < kSlots; ++i) {
         if (known[i] == fn) { slot = i; break; }
         if (known[i] == nullptr) { known[i] = fn; slot = i; break; }
     }
-    if (slot >= 0 && dev >= 0 && done[slot][dev]) return NERF_OK;
+    if (slot >= 0 && dev >= 0 && set_bytes[slot][dev] >= bytes) return NERF_OK;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return nerf_fail(NERF_E_LAUNCH, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
-    if (slot >= 0 && dev >= 0) done[slot][dev] = 1;
+    if (slot >= 0 && dev >= 0) set_bytes[slot][dev] = bytes;
     return NERF_OK;
 }
 

@@ -145,6 +145,14 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
     return rgb
 
 
+def _disjoint(a: Optional[Tensor], b: Optional[Tensor]) -> bool:
+    """Two gradient sinks (flat fp32 buffers, or None) occupy different memory."""
+    if a is None or b is None:
+        return True
+    a0, b0 = a.data_ptr(), b.data_ptr()
+    return a0 + a.numel() * a.element_size() <= b0 or b0 + b.numel() * b.element_size() <= a0
+
+
 def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, rays_o: Tensor, rays_d: Tensor,
                              near: float, far: float, num_coarse: int = 64, num_fine: int = 128,
                              device: str = 'cuda', white_background: bool = True, chunk_size: int = 8192, *,
@@ -180,12 +188,21 @@ def render_nerf_hierarchical(coarse: torch.nn.Module, fine: torch.nn.Module, ray
     sink_c = grad_sink(coarse, pc) if tc_train else None
     sink_f = grad_sink(fine, pf) if tf_train else None
     density_only = not coarse_rgb and not tc_train and not tf_train
+    if rays_o.shape[0] == 0:   # nothing to render (a rank whose slice of the rays is empty)
+        empty = rays_o.new_zeros((0, 3))
+        res = (None if density_only else empty, rays_o.new_zeros((0, 3)))
+        if return_extras:
+            res += (rays_o.new_zeros((0, num_coarse + num_fine)), rays_o.new_zeros((0,)), rays_o.new_zeros((0,)))
+        return res
+    # Two backward chains may only run side by side when they add into different memory: one module used as both
+    # networks (or two modules sharing a bucket slice) would have two streams read-modify-write the same gradients.
+    overlap = ops.OVERLAP_BACKWARD and tc_train and tf_train and coarse is not fine and _disjoint(sink_c, sink_f)
     out_c, out_f, extras = [], [], []
     for ci, i in enumerate(range(0, rays_o.shape[0], chunk_size)):
         o, d = rays_o[i:i + chunk_size], rays_d[i:i + chunk_size]
         R = o.shape[0]
         t_c, deltas_c = _t_and_deltas(near, far, num_coarse, rays_o.device, None if u is None else u[ci].to(rays_o.device))
-        if ops.OVERLAP_BACKWARD and tc_train and tf_train:
+        if overlap:
             # the coarse pass goes to a side stream so that autograd runs its backward there, concurrently with
             # the fine network's backward; in the forward direction the fine pass waits for it as before
             main, side = torch.cuda.current_stream(rays_o.device), ops.side_stream(rays_o.device)

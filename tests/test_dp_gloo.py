@@ -1,6 +1,6 @@
 """world_size-2 data-parallel path on CPU (gloo): flat gradient bucket, shared uniform draw,
 ray sharding.  The per-rank gradient producer is the oracle model (the HIP kernels need a GPU;
-tests/test_dp_gpu.py runs the same check with the kernels); what is under test is the product's host
+tests/test_a_dp_gpu.py runs the same check with the kernels); what is under test is the product's host
 logic in nerf/parallel.py: after all_reduce_mean the bucket equals the single-process gradient of
 the full batch."""
 import os

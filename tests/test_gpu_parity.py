@@ -269,9 +269,16 @@ def test_repack_after_parameter_update():
 # ----------------------------------------------------------------------------- renderer
 @pytest.mark.parametrize("tag", ["nerf_S64_onechunk", "nerf_S256_chunk24", "nerf_S64_black",
                                  "siren_S64_onechunk", "siren_S256_chunk24"])
-def test_render_golden(golden, tag):
+@pytest.mark.parametrize("family", ["g6", "g6k"])
+def test_render_golden(golden, tag, family):
+    """render_nerf + MSE + backward against the reference's own outputs (rendering.py:156-226, train.py:179-181).
+    g6k: the same cases on rays chosen so that no sample sits within 3e-6 of a ReLU kink
+    (tests/golden/make_golden_kinkfree.py) -- every gradient tensor's norm at 1e-5 and its stored subsample element by
+    element.  g6: rays as they fell; a ReLU decision within fp32 rounding of zero differs between any two matmul
+    implementations and moves a whole gradient path, so the norms are held to 3e-5 there (the forward is continuous
+    across a kink and stays at 1e-5), the subsamples to ten times the kink-free bound."""
     from nerf.rendering import render_nerf
-    z = golden(f"g6_{tag}.npz")
+    z = golden(f"{family}_{tag}.npz")
     R, S, chunk, _, wb = (int(v) for v in z["cfg"])
     model, _ = make_model(tag.split("_")[0])
     us = [T(u).to(DEV) for u in z["us"]]
@@ -281,9 +288,17 @@ def test_render_golden(golden, tag):
     loss = torch.nn.functional.mse_loss(rgb, T(z["target"]).to(DEV))
     assert abs(float(loss.detach()) - float(z["loss"])) <= RTOL * float(z["loss"])
     loss.backward()
+    kink_free = family == "g6k"
     for n, p in model.named_parameters():
         gn = float(z["gnorm." + n])
-        assert abs(float(p.grad.norm()) - gn) <= 3 * RTOL * gn, (n, float(p.grad.norm()), gn)
+        ntol = RTOL if kink_free else 3 * RTOL
+        assert abs(float(p.grad.norm()) - gn) <= ntol * gn, (n, float(p.grad.norm()), gn)
+        f = p.grad.reshape(-1)
+        step = max(1, f.numel() // 97)
+        sub = f[::step][:97].cpu().numpy()
+        # element by element, relative to the tensor's rms entry (the bound test_model_golden_forward_backward uses)
+        etol = (3 if kink_free else 30) * RTOL * gn / math.sqrt(f.numel()) + 1e-9
+        assert np.abs(sub - z["gsub." + n]).max() <= etol, (n, float(np.abs(sub - z["gsub." + n]).max()), etol)
 
 
 @pytest.mark.parametrize("tag", ["nerf", "siren"])

@@ -92,8 +92,9 @@ def test_g5_composite(golden, wb):
 
 @pytest.mark.parametrize("tag", ["nerf_S64_onechunk", "nerf_S256_chunk24", "nerf_S64_black",
                                  "siren_S64_onechunk", "siren_S256_chunk24"])
-def test_g6_render_end_to_end(golden, tag):
-    z = golden(f"g6_{tag}.npz")
+@pytest.mark.parametrize("family", ["g6", "g6k"])   # g6k: rays chosen clear of every ReLU kink (make_golden_kinkfree.py)
+def test_g6_render_end_to_end(golden, tag, family):
+    z = golden(f"{family}_{tag}.npz")
     R, S, chunk, _, wb = (int(v) for v in z["cfg"])
     params, fwd = _model_case(tag.split("_")[0])
     for p in params.values():
