@@ -67,11 +67,12 @@ def main(argv=None):
     ap.add_argument('--output', type=str, default='rendered_frames')
     ap.add_argument('--resolution', type=int, default=None, help='override H=W (default: the test image size)')
     ap.add_argument('--precision', choices=['fp32', 'bf16', 'bf16x3'], default='fp32')
+    ap.add_argument('--one-device', action='store_true', help='rehearsal only: every rank renders on cuda:0')
     args = ap.parse_args(argv)
     cfg = parse_config(args.config)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0")))
     if not torch.cuda.is_available():
         raise RuntimeError("this build needs a HIP device (no CPU path)")
     device = torch.device("cuda", torch.cuda.current_device())
@@ -114,6 +115,10 @@ def main(argv=None):
         H = W = args.resolution
     angles = np.linspace(-180, 180, n_poses + 1)[:-1]
     for i in poses_for_rank(n_poses, rank, world):
+        # The stratified jitter stays on at render time (rendering.py:26 has no switch).  Its generator is re-seeded
+        # per pose, so that a frame does not depend on which rank rendered it or on the frames before it: the frames
+        # of a pose-sharded run are bit for bit those of a single process.
+        torch.manual_seed(42 + i)
         c2w = torch.from_numpy(pose_spherical(float(angles[i]), -30.0, 4.0))[None].to(device)
         ro, rd = compute_rays_device(H, W, c2w, focal)
         with torch.no_grad():

@@ -407,6 +407,64 @@ def test_fused_adam_matches_torch_adam(hip):
     assert rel(p, pr) < 1e-6 and (p - pr.detach()).abs().max() < 1e-6
 
 
+def test_fused_adam_applies_the_gradient_scale(hip):
+    """grad_scale of nerf_adam_step (where data-parallel training folds the 1/world factor): the moments after a
+    step with (g, scale s) equal those of a step with the pre-scaled gradient -- exp_avg scales as s, exp_avg_sq
+    as s^2, so a dropped or wrong factor cannot hide behind Adam's near scale-invariance -- and with an eps large
+    enough to matter (1e-2) the parameters agree as well."""
+    torch.manual_seed(1)
+    n = 50021
+    p0, g = torch.randn(n, device=DEV), torch.randn(n, device=DEV) * 1e-2
+    for s in (0.5, 0.125, 1.0 / 3.0):
+        pa, ma, va = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        pb, mb, vb = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        gs = g * s
+        for step in (1, 2):
+            hip.adam_step(pa, g, ma, va, step, 5e-4, 0.9, 0.999, 1e-2, grad_scale=s)
+            hip.adam_step(pb, gs, mb, vb, step, 5e-4, 0.9, 0.999, 1e-2, grad_scale=1.0)
+        assert rel(ma, mb) < 1e-6 and rel(va, vb) < 1e-6 and rel(pa - p0, pb - p0) < 1e-5
+        # and against the unscaled step they differ by exactly the factor
+        pc, mc, vc = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        hip.adam_step(pc, g, mc, vc, 1, 5e-4, 0.9, 0.999, 1e-2, grad_scale=1.0)
+        m1, v1 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        hip.adam_step(p0.clone(), g, m1, v1, 1, 5e-4, 0.9, 0.999, 1e-2, grad_scale=s)
+        assert rel(m1, mc * s) < 1e-6 and rel(v1, vc * s * s) < 1e-6
+
+
+def test_one_network_as_coarse_and_fine_accumulates_in_one_sink(hip):
+    """A single module passed as both networks of render_nerf_hierarchical with a flat bucket: both passes add
+    into the SAME gradient slice, so their backward chains must not run on two streams at once (non-atomic
+    read-modify-write).  The gradient equals the sum of the per-pass gradients taken separately, and is
+    bit-identical with the two-stream overlap switched off."""
+    from nerf import ops, parallel
+    from nerf.rendering import render_nerf_hierarchical
+    net, _ = make_model("nerf")
+    o, d = rays(96, 91)
+    o, d = o.to(DEV), d.to(DEV)
+    u = [torch.rand(16, generator=torch.Generator().manual_seed(92)).to(DEV)]
+    uf = [torch.rand(96, 24, generator=torch.Generator().manual_seed(93)).to(DEV)]
+    tgt = torch.rand(96, 3, generator=torch.Generator().manual_seed(94)).to(DEV)
+    flat = parallel.FlatParameters(net)
+
+    def grad(overlap, which=(1.0, 1.0)):
+        old = ops.OVERLAP_BACKWARD
+        ops.OVERLAP_BACKWARD = overlap
+        try:
+            flat.zero_grad()
+            rc, rf = render_nerf_hierarchical(net, net, o, d, 2.0, 6.0, 16, 24, device=DEV, u=u, u_fine=uf)
+            (which[0] * torch.nn.functional.mse_loss(rc, tgt) + which[1] * torch.nn.functional.mse_loss(rf, tgt)).backward()
+            torch.cuda.synchronize()
+            return flat.grad.clone()
+        finally:
+            ops.OVERLAP_BACKWARD = old
+
+    g_on, g_off = grad(True), grad(False)
+    assert torch.equal(g_on, g_off)
+    g_c, g_f = grad(False, (1.0, 0.0)), grad(False, (0.0, 1.0))
+    assert float(g_c.abs().max()) > 0 and float(g_f.abs().max()) > 0
+    assert rel(g_on, g_c + g_f) < 1e-6
+
+
 def test_flat_bucket_receives_gradients_directly(hip):
     """With parallel.FlatParameters the backward kernels add into the flat gradient bucket themselves
     (accumulate flag of nerf_mlp_bwd_weights): same values as the per-tensor autograd path, accumulation
@@ -956,6 +1014,16 @@ def test_render_nerf_no_rays():
     model, _ = make_model("nerf")
     out = render_nerf(model, torch.zeros(0, 3), torch.zeros(0, 3), 2.0, 6.0, num_samples=16, device=DEV)
     assert out.shape == (0, 3)
+    # the coarse + fine renderer as well (a rank whose slice of the rays is empty), every return form
+    from nerf.rendering import render_nerf_hierarchical
+    e = torch.zeros(0, 3)
+    rc, rf = render_nerf_hierarchical(model, model, e, e, 2.0, 6.0, 16, 24, device=DEV)
+    assert rc.shape == (0, 3) and rf.shape == (0, 3)
+    rc, rf, w, depth, acc = render_nerf_hierarchical(model, model, e, e, 2.0, 6.0, 16, 24, device=DEV, return_extras=True)
+    assert w.shape == (0, 40) and depth.shape == (0,) and acc.shape == (0,)
+    with torch.no_grad():
+        rc, rf = render_nerf_hierarchical(model, model, e, e, 2.0, 6.0, 16, 24, device=DEV, coarse_rgb=False)
+    assert rc is None and rf.shape == (0, 3)
 
 
 # ----------------------------------------------------------------------------- gradients wrt the inputs
