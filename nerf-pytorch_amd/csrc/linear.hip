@@ -166,9 +166,17 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     out[i] = s;
 }
 
+// Sample slices of the weight gradient: about 2048 samples each up to 64 slices, then longer slices; beyond 4096
+// samples per slice the slice count grows again (up to 256).  A slice is summed sequentially in one fp32 accumulator,
+// so its length sets the rounding error of the gradient: at 16384 samples per slice (the old cap of 64 slices at
+// 1,048,576 samples) a 63-input layer's gradient was 1e-4 off the float64 value, at 4096 it is about 1e-6.
 int splits_for(int64_t M) {
     int64_t z = M / 2048;
-    return (int)(z < 1 ? 1 : z > 64 ? 64 : z);
+    if (z > 64) {
+        z = M / 4096;
+        z = z < 64 ? 64 : z > 256 ? 256 : z;
+    }
+    return (int)(z < 1 ? 1 : z);
 }
 
 }  // namespace

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "mlp_layout.h"
 #include "sincos.h"
+#include "sincos_table.h"
 
 #include <type_traits>
 
@@ -36,6 +37,66 @@ constexpr int LDA = 260;
 constexpr int ACT_FLOATS = TR * LDA;
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIN = 2 };
+
+// (sin, cos) of 2*pi*k/256 for the table form of the sine/cosine (sincos.h, nerf_sincosf_tab).  Kernels with sine
+// epilogues copy it into the FIRST 2 KiB of their LDS once per workgroup, de-interleaved (sin[256], then cos[256]), and
+// read it from there: LDS reads cost the matrix pipe nothing, vector-ALU instructions do.
+constexpr int SINCOS_TAB_FLOATS = 2 * NERF_SINCOS_TABLE_ENTRIES;
+static __device__ const float g_sincos_table[SINCOS_TAB_FLOATS] = {NERF_SINCOS_TABLE_VALUES};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// `lds0` must be the start of the kernel's LDS allocation (byte offset 0: the table reads below address it through
+// the instruction's immediate offset alone); traps otherwise.
+__device__ __forceinline__ void load_sincos_table(float* lds0, int tid) {
+    static_assert(NERF_SINCOS_TABLE_ENTRIES == 256, "one entry per thread of a 256-thread workgroup");
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds0 != 0u) __builtin_trap();
+    const f32x2 e = *reinterpret_cast<const f32x2*>(g_sincos_table + 2 * tid);
+    lds0[tid] = e[0];
+    lds0[NERF_SINCOS_TABLE_ENTRIES + tid] = e[1];
+}
+
+// nerf_sincosf_tab for two values at once, split in two halves so that the table reads of several pairs can be in
+// flight together.  Same operations in the same order as the scalar form (bitwise the same results), written on
+// 2-vectors so that they become packed instructions (v_pk_fma_f32 ...): 13 per pair, plus one SDWA shift per value
+// for the table offset (byte 0 of the rounded sum's bit pattern = k mod 256, times 4 = the LDS byte address, the
+// table sitting at LDS offset 0).  The four table reads of a pair are VOLATILE loads: ordinary ones are merged into
+// two-address reads (one value's sin and cos), whose result pairs then have to be shuffled into the (value a,
+// value b) pairs the packed instructions want -- two moves per value; volatile ones stay single and land where the
+// packed instructions read them.  The compiler still tracks them (it places the waits), unlike reads issued from
+// inline assembly.
+struct SinCosPair {
+    f32x2 r;      // reduced arguments
+    f32x2 S, C;   // table entries of the two values
+};
+typedef const volatile __attribute__((address_space(3))) float* lds_table_ptr;
+__device__ __forceinline__ void sincos_tab_issue(f32x2 x, SinCosPair& p) {
+#pragma clang fp contract(off)   // the operations as written: the sequence the host sweep has checked
+    const f32x2 magic = {12582912.0f, 12582912.0f};
+    const f32x2 tm = __builtin_elementwise_fma(x, (f32x2){40.743665431525205956834243423364f, 40.743665431525205956834243423364f}, magic);
+    const f32x2 kf = tm - magic;
+    const f32x2 r = __builtin_elementwise_fma(-kf, (f32x2){0.024543693289160728f, 0.024543693289160728f}, x);
+    p.r = __builtin_elementwise_fma(-kf, (f32x2){-6.8299044198028014e-10f, -6.8299044198028014e-10f}, r);
+    // (the elements go through plain floats: __builtin_bit_cast applied directly to an element of an ext_vector
+    // reads element 0 whatever the index with this compiler)
+    const float tm0 = tm[0], tm1 = tm[1];
+    unsigned o0, o1;
+    asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+                 : "=v"(o0) : "v"(2u), "v"(tm0));
+    asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+                 : "=v"(o1) : "v"(2u), "v"(tm1));
+    p.S[0] = *(lds_table_ptr)(size_t)o0;
+    p.S[1] = *(lds_table_ptr)(size_t)o1;
+    p.C[0] = *(lds_table_ptr)(size_t)(o0 + 4 * NERF_SINCOS_TABLE_ENTRIES);
+    p.C[1] = *(lds_table_ptr)(size_t)(o1 + 4 * NERF_SINCOS_TABLE_ENTRIES);
+}
+__device__ __forceinline__ void sincos_tab_finish(const SinCosPair& p, f32x2& sn, f32x2& cs) {
+#pragma clang fp contract(off)
+    const f32x2 z = p.r * p.r;
+    const f32x2 w = __builtin_elementwise_fma(z, (f32x2){-0.16666667f, -0.16666667f}, (f32x2){1.0f, 1.0f});
+    const f32x2 hr = p.r * (f32x2){0.5f, 0.5f};
+    sn = __builtin_elementwise_fma(p.r, __builtin_elementwise_fma(-p.S, hr, p.C * w), p.S);
+    cs = __builtin_elementwise_fma(-p.r, __builtin_elementwise_fma(p.C, hr, p.S * w), p.C);
+}
 
 #define LAYER_SYNC() __syncthreads()
 
@@ -216,15 +277,15 @@ __device__ __forceinline__ int acc_row(int mi, int g, int lane) { return 32 * mi
 //           so a thread stores (and the data-gradient kernel, whose tiles have the same register map, loads)
 //           16 fully coalesced 16-byte pieces instead of 64 strided 4-byte ones.
 // relu_mask (may be NULL): receives this lane's MT*32 (v > 0) bits, accumulator order.
-template <int NT, int ACT, bool STORE_COS>
-__device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], int ncol0, int lane,
-                                             float* __restrict__ gcos, int ldg,
-                                             mask_t* __restrict__ relu_mask = nullptr) {
-    unsigned mlo = 0u, mhi = 0u;
-    // derivative tile: buffer stores (one resource, one lane offset, the element in the constant offset)
+// Sine layers need the sine/cosine table in the first 2 KiB of LDS (load_sincos_table).
+// Sine layers: v = sin(z) to LDS, cos(z) to the workspace (training), through the table form of the sine/cosine:
+// per 16-register accumulator tile the table reads of all eight value pairs are issued first, then finished.
+template <int NT, bool STORE_COS>
+__device__ __forceinline__ void sine_epilogue(float* act, f32x16 (&acc)[MT][NT], int ncol0, int lane,
+                                              float* __restrict__ gcos, int ldg) {
     __amdgpu_buffer_rsrc_t cos_rsrc;
     int cos_voff = 0;
-    if constexpr (STORE_COS && ACT == ACT_SIN) {
+    if constexpr (STORE_COS) {
         cos_rsrc = make_rsrc(gcos, (unsigned)(TR * ldg * 4));
         if constexpr (NT == 1) cos_voff = (4 * (lane >> 5) * ldg + ncol0 + (lane & 31)) * 4;
         else cos_voff = ((ncol0 / (32 * NT)) * 64 + lane) * 16;   // tid * 16 bytes
@@ -234,12 +295,60 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], 
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int col = ncol0 + 32 * ni + (lane & 31);
-            f32x4 cpiece = {0.f, 0.f, 0.f, 0.f};
+            SinCosPair pr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sincos_tab_issue((f32x2){acc[mi][ni][2 * q], acc[mi][ni][2 * q + 1]}, pr[q]);
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                f32x2 sa, ca, sb, cb;
+                sincos_tab_finish(pr[q], sa, ca);
+                sincos_tab_finish(pr[q + 1], sb, cb);
+                const int g = 2 * q;   // registers g .. g+3: rows (g&3) + 8*(g>>2) + {0,1,2,3} of the tile
+                act[acc_row(mi, g, lane) * LDA + col] = sa[0];
+                act[acc_row(mi, g + 1, lane) * LDA + col] = sa[1];
+                act[acc_row(mi, g + 2, lane) * LDA + col] = sb[0];
+                act[acc_row(mi, g + 3, lane) * LDA + col] = sb[1];
+                if constexpr (STORE_COS) {
+                    if constexpr (NT == 1) {
+                        const float cv[4] = {ca[0], ca[1], cb[0], cb[1]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cv[e]), cos_rsrc, cos_voff,
+                                                                  ((32 * mi + ((g + e) & 3) + 8 * ((g + e) >> 2)) * ldg + 32 * ni) * 4, 0);
+                    } else {
+                        // The piece offset goes into the VGPR offset and the scalar offset stays the constant 0 on
+                        // purpose.  With the offset in an SGPR, hipcc lets a VALU instruction overwrite the four data
+                        // registers in the very next slot (its hazard model exempts stores with a register soffset), and
+                        // on gfx950 the store then writes a mix of old and new values for some 4-lane groups once several
+                        // workgroups keep the memory pipeline busy (seen as run-to-run differences of the derivative
+                        // tiles from 1024 tiles on).  With an immediate soffset the compiler inserts the wait state.
+                        const f32x4 cpiece = {ca[0], ca[1], cb[0], cb[1]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, cpiece), cos_rsrc,
+                                                               cos_voff + ((mi * NT + ni) * 4 + (g >> 2)) * 256 * 16, 0, 2);
+                    }
+                }
+            }
+        }
+}
+
+template <int NT, int ACT, bool STORE_COS>
+__device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], int ncol0, int lane,
+                                             float* __restrict__ gcos, int ldg,
+                                             mask_t* __restrict__ relu_mask = nullptr) {
+    if constexpr (ACT == ACT_SIN) {
+        sine_epilogue<NT, STORE_COS>(act, acc, ncol0, lane, gcos, ldg);
+        return;
+    }
+    unsigned mlo = 0u, mhi = 0u;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int col = ncol0 + 32 * ni + (lane & 31);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int row = acc_row(mi, g, lane);
                 float v = acc[mi][ni][g];
-                float c = 0.f;
                 if constexpr (ACT == ACT_RELU) {
                     // max(v, 0) as ONE instruction: fmaxf (and every intrinsic the compiler folds back into it) puts a
                     // canonicalising v_max_f32 v, v, v in front, and VALU instructions are matrix-pipe time here
@@ -253,29 +362,7 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], 
                         else mhi = __builtin_amdgcn_alignbit(mhi, t, 31);
                     }
                 }
-                if constexpr (ACT == ACT_SIN) {
-                    float s;
-                    nerf_sincosf_bounded(v, &s, &c);   // layer input is a sine layer's output: |v| <= sum|w| + |b|
-                    v = s;
-                }
                 act[row * LDA + col] = v;
-                if constexpr (STORE_COS && ACT == ACT_SIN) {
-                    if constexpr (NT == 1) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), cos_rsrc, cos_voff,
-                                                              ((32 * mi + (g & 3) + 8 * (g >> 2)) * ldg + 32 * ni) * 4, 0);
-                    } else {
-                        cpiece[g & 3] = c;
-                        if ((g & 3) == 3)
-                            // The piece offset goes into the VGPR offset and the scalar offset stays the constant 0 on
-                            // purpose.  With the offset in an SGPR, hipcc lets a VALU instruction overwrite the four data
-                            // registers in the very next slot (its hazard model exempts stores with a register soffset), and
-                            // on gfx950 the store then writes a mix of old and new values for some 4-lane groups once several
-                            // workgroups keep the memory pipeline busy (seen as run-to-run differences of the derivative
-                            // tiles from 1024 tiles on).  With an immediate soffset the compiler inserts the wait state.
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, cpiece), cos_rsrc,
-                                                                   cos_voff + ((mi * NT + ni) * 4 + (g >> 2)) * 256 * 16, 0, 2);
-                    }
-                }
             }
         }
     if constexpr (ACT == ACT_RELU && NT == 2) {

@@ -173,6 +173,7 @@ struct FwdArgs {
 
 constexpr int XIN_FLOATS = TR * 8;
 constexpr int FWD_LDS_BYTES = (ACT_FLOATS + XIN_FLOATS + TR) * 4;
+constexpr int SIREN_FWD_LDS_BYTES = FWD_LDS_BYTES + SINCOS_TAB_FLOATS * 4;   // + the sine/cosine table
 
 __device__ __forceinline__ float norm_coord(float p, float nearf, float spanf) {
 #pragma clang fp contract(off)  // each operation rounded on its own, as the reference's tensor ops are
@@ -201,6 +202,13 @@ __device__ __forceinline__ void load_inputs(const FwdArgs& a, size_t m0, float* 
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xin[tid * 8 + c] = x[c]; xin[tid * 8 + 3 + c] = d[c]; }
+        // xin[6] (a padding column of row 0) = the tile's largest |position coordinate|: lets the first Siren layer
+        // bound its sine arguments once per tile.  Infinities survive the maximum; a NaN coordinate does not, and
+        // does not need to (NaN in, NaN out on either sine path).
+        float big = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fabsf(x[2]));
+#pragma unroll
+        for (int off = TR / 2; off >= 1; off >>= 1) big = fmaxf(big, __shfl_xor(big, off, TR));
+        if (tid == 0) xin[6] = big;
     }
 }
 
@@ -439,8 +447,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void siren_fwd_kernel(FwdArgs a) {
     using namespace lay;
     using namespace lay::siren;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* act = smem;
-    float* xin = smem + ACT_FLOATS;
+    float* act = smem + SINCOS_TAB_FLOATS;   // the sine/cosine table occupies the first 2 KiB (load_sincos_table)
+    float* xin = act + ACT_FLOATS;
     float* sraw_s = xin + XIN_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -450,6 +458,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void siren_fwd_kernel(FwdArgs a) {
     const size_t Mp = a.Mp;
     auto wsp = [&](size_t off, int width) -> float* { return TRAIN ? ws + off * Mp + m0 * width : nullptr; };
 
+    load_sincos_table(smem, tid);
     load_inputs(a, m0, xin, tid);
     __syncthreads();
     if constexpr (TRAIN) {
@@ -458,21 +467,52 @@ __global__ __launch_bounds__(256, WG_PER_CU) void siren_fwd_kernel(FwdArgs a) {
             *reinterpret_cast<f32x4*>(ws + WS_X * Mp + (m0 + tid) * 4) = v;
         }
     }
-    // layer 0 (3 -> 256, sin(30 z)) on the VALU: thread = output column
+    // layer 0 (3 -> 256, sin(30 z)) on the VALU: thread = output column, 16 samples (8 value pairs of the table-form
+    // sine/cosine) in flight at a time.  The table form holds for |30 z| <= 1e5; whether this thread's column can
+    // leave that range is decided once per tile from the largest |coordinate| of the tile (xin[6], written above),
+    // not per value: |30 z| <= 30 ((|w0| + |w1| + |w2|) max|x| + |b|).
     {
         const float w0 = pk[W0 + tid * 3], w1 = pk[W0 + tid * 3 + 1], w2 = pk[W0 + tid * 3 + 2], b = pk[BIAS + tid];
         float* gc = wsp(WS_C, H);
-        for (int s = 0; s < TR; ++s) {
-            const float z = fmaf(xin[s * 8 + 2], w2, fmaf(xin[s * 8 + 1], w1, fmaf(xin[s * 8], w0, b)));
-            float sn, cs;
-            nerf_sincosf(mul_rn(30.0f, z), &sn, &cs);
-            act[s * LDA + tid] = sn;
-            if constexpr (TRAIN) {
-                // the derivative tile in the accumulator order the data-gradient kernel reads (fwd_epilogue):
-                // element (row s, column tid) is register g of lane (tid & 31) + 32*h of wave tid / 64
-                const int mi = s >> 5, rr = s & 31, hh = (rr >> 2) & 1, g = (rr & 3) + 4 * (rr >> 3);
-                const int owner = (tid >> 6) * 64 + (tid & 31) + 32 * hh, ni = (tid >> 5) & 1;
-                gc[(((mi * 2 + ni) * 4 + (g >> 2)) * 256 + owner) * 4 + (g & 3)] = 30.0f * cs;
+        const float bound = 30.0f * ((fabsf(w0) + fabsf(w1) + fabsf(w2)) * xin[6] + fabsf(b));
+        // the derivative tile in the accumulator order the data-gradient kernel reads (sine_epilogue): element
+        // (row s, column tid) is register g of lane (tid & 31) + 32*h of wave tid / 64; four consecutive rows
+        // s = 4j .. 4j+3 are the four floats of one 16-byte piece
+        auto piece_of = [&](int s) {
+            const int mi = s >> 5, rr = s & 31, hh = (rr >> 2) & 1, g = 4 * (rr >> 3);
+            const int owner = (tid >> 6) * 64 + (tid & 31) + 32 * hh, ni = (tid >> 5) & 1;
+            return gc + (((mi * 2 + ni) * 4 + (g >> 2)) * 256 + owner) * 4;
+        };
+        auto pre = [&](int s) { return mul_rn(30.0f, fmaf(xin[s * 8 + 2], w2, fmaf(xin[s * 8 + 1], w1, fmaf(xin[s * 8], w0, b)))); };
+        if (bound <= 9.9e4f) {
+#pragma unroll 1
+            for (int s0 = 0; s0 < TR; s0 += 16) {
+                SinCosPair pr[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sincos_tab_issue((f32x2){pre(s0 + 2 * q), pre(s0 + 2 * q + 1)}, pr[q]);
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    f32x2 sa, ca, sb, cb;
+                    sincos_tab_finish(pr[q], sa, ca);
+                    sincos_tab_finish(pr[q + 1], sb, cb);
+                    const int s = s0 + 2 * q;
+                    act[s * LDA + tid] = sa[0];
+                    act[(s + 1) * LDA + tid] = sa[1];
+                    act[(s + 2) * LDA + tid] = sb[0];
+                    act[(s + 3) * LDA + tid] = sb[1];
+                    if constexpr (TRAIN)
+                        *reinterpret_cast<f32x4*>(piece_of(s)) = f32x4{30.0f * ca[0], 30.0f * ca[1], 30.0f * cb[0], 30.0f * cb[1]};
+                }
+            }
+        } else {   // (also NaN bounds) value by value through the library's full-range path where needed
+#pragma unroll 1
+            for (int s = 0; s < TR; ++s) {
+                const float arg = pre(s);
+                float sn, cs;
+                if (fabsf(arg) <= 1.0e5f) nerf_sincosf_tab_soa(arg, smem, &sn, &cs);
+                else sincosf(arg, &sn, &cs);
+                act[s * LDA + tid] = sn;
+                if constexpr (TRAIN) piece_of(s & ~3)[s & 3] = 30.0f * cs;
             }
         }
     }
@@ -570,14 +610,14 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
         }
     } else {
         if (workspace) {
-            if ((rc = nerf_set_lds(siren_fwd_kernel<true>, FWD_LDS_BYTES))) return rc;
-            siren_fwd_kernel<true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+            if ((rc = nerf_set_lds(siren_fwd_kernel<true>, SIREN_FWD_LDS_BYTES))) return rc;
+            siren_fwd_kernel<true><<<(unsigned)tiles, 256, SIREN_FWD_LDS_BYTES, st>>>(a);
         } else if (colors) {
-            if ((rc = nerf_set_lds(siren_fwd_kernel<false>, FWD_LDS_BYTES))) return rc;
-            siren_fwd_kernel<false><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+            if ((rc = nerf_set_lds(siren_fwd_kernel<false>, SIREN_FWD_LDS_BYTES))) return rc;
+            siren_fwd_kernel<false><<<(unsigned)tiles, 256, SIREN_FWD_LDS_BYTES, st>>>(a);
         } else {
-            if ((rc = nerf_set_lds(siren_fwd_kernel<false, true>, FWD_LDS_BYTES))) return rc;
-            siren_fwd_kernel<false, true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+            if ((rc = nerf_set_lds(siren_fwd_kernel<false, true>, SIREN_FWD_LDS_BYTES))) return rc;
+            siren_fwd_kernel<false, true><<<(unsigned)tiles, 256, SIREN_FWD_LDS_BYTES, st>>>(a);
         }
     }
     return nerf_check_launch("nerf_mlp_fwd");

@@ -50,6 +50,45 @@ NERF_HD void nerf_sincosf_bounded(float x, float* sn, float* cs) {
 #endif
 }
 
+// Table form: x = k*(2 pi/256) + r with |r| <= pi/256, (S, C) = (sin, cos) of k*(2 pi/256) from a 256-entry table
+// (sincos_table.h; in LDS on the device), and with w = 1 - r^2/6 (sin r = r w, next term < 3e-12) and
+// cos r - 1 = -r^2/2 (next term < 1e-9):
+//     sin x = S + r (C w - S r/2),   cos x = C - r (S w + C r/2).
+// No quadrant logic, no selects: 13 floating-point operations that pair up into packed instructions, one integer
+// operation for the table index and one table read per value, against 15 + 8 unpackable ones of the polynomial
+// form above -- in the sine epilogues of the fused kernels every vector instruction is matrix-pipe time.
+// Reduction: 2 pi/256 = P1 + P2 with P1 the nearest fp32.  x - k*P1 comes out of ONE fused multiply-add exactly (it
+// is a multiple of 2^-29 below 2^-5 whatever the size of k), so two constants are enough and the error stays at
+// 6.3e-8 absolute up to |x| = 1e5, where the rounding by magic-number addition runs out of integer bits
+// (tests/host/sincos_sweep.cpp sweeps both forms against double precision).
+// `tab` holds NERF_SINCOS_TABLE_ENTRIES (sin, cos) pairs.
+// SIN_AT(k), COS_AT(k): where the table keeps its entries (interleaved pairs on the host, two arrays in LDS).
+template <int STRIDE, int COS_OFFSET>
+NERF_HD void nerf_sincosf_tab_impl(float x, const float* tab, float* sn, float* cs) {
+#if defined(__clang__)
+#pragma clang fp contract(off)   // the operations as written (the sequence the host sweep checks), on every compiler
+#endif
+    const float tm = fmaf(x, 40.743665431525205956834243423364f, 12582912.0f);   // x * 256/(2 pi), rounded to an integer
+    const float kf = tm - 12582912.0f;
+    float r = fmaf(-kf, 0.024543693289160728f, x);        // exact
+    r = fmaf(-kf, -6.8299044198028014e-10f, r);
+    const unsigned k = __builtin_bit_cast(unsigned, tm) & 255u;   // low mantissa bits = the integer (two's complement)
+    const float S = tab[STRIDE * k], C = tab[STRIDE * k + COS_OFFSET];
+    const float z = r * r;
+    const float w = fmaf(z, -0.16666667f, 1.0f);
+    const float hr = r * 0.5f;
+    *sn = fmaf(r, fmaf(-S, hr, C * w), S);
+    *cs = fmaf(-r, fmaf(C, hr, S * w), C);
+}
+// table of 256 interleaved (sin, cos) pairs (sincos_table.h as it stands)
+NERF_HD void nerf_sincosf_tab(float x, const float* tab, float* sn, float* cs) {
+    nerf_sincosf_tab_impl<2, 1>(x, tab, sn, cs);
+}
+// table as two arrays, sin[256] then cos[256] (the LDS copy of the fused kernels)
+NERF_HD void nerf_sincosf_tab_soa(float x, const float* tab, float* sn, float* cs) {
+    nerf_sincosf_tab_impl<1, 256>(x, tab, sn, cs);
+}
+
 NERF_HD void nerf_sincosf(float x, float* sn, float* cs) {
     if (!(fabsf(x) <= 1.0e5f)) {  // also catches NaN
         sincosf(x, sn, cs);

