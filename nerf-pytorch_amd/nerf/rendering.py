@@ -97,6 +97,9 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
     compositing kernel on its outputs), or for any other nn.Module the reference's sequence
     sample -> flatten -> model.forward -> composite with HIP sampling/compositing kernels.
 
+    Rays that require grad take the second route as well, with positions built from differentiable tensor
+    operations, so that d rgb / d rays_o and d rays_d exist as they do in the reference.
+
     Keyword-only extras: `u` = list of per-chunk uniform draws (replaces torch.rand, for parity
     tests and for data-parallel ranks that must share the draw); `return_extras` = also return
     (weights [N,S], depth [N], acc [N]).
@@ -110,7 +113,11 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
         if return_extras:
             return empty, rays_o.new_zeros((0, num_samples)), rays_o.new_zeros((0,)), rays_o.new_zeros((0,))
         return empty
-    fused = _fused_model(model)
+    # Gradients with respect to the rays (the reference's render_nerf is transparent to autograd in rays_o / rays_d,
+    # rendering.py:59-62,223; none of its callers asks for them): positions from differentiable tensor operations, the
+    # model through its layer-wise kernels (which have input gradients), the compositing kernel on top.
+    rays_need_grad = torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)
+    fused = _fused_model(model) and not rays_need_grad
     if fused:
         model._check_supported()
         params = model.ordered_parameters()
@@ -131,7 +138,10 @@ def render_nerf(model: torch.nn.Module, rays_o: Tensor, rays_d: Tensor, near: fl
             else:
                 outs.append(res)
         else:
-            pos = _hip.sample_positions(o_chunk, d_chunk, t, False, near, far).reshape(-1, 3)
+            if rays_need_grad:   # o + t*d as the reference forms it: one multiplication, one addition per element
+                pos = (o_chunk.unsqueeze(1) + t.view(1, -1, 1) * d_chunk.unsqueeze(1)).reshape(-1, 3)
+            else:
+                pos = _hip.sample_positions(o_chunk, d_chunk, t, False, near, far).reshape(-1, 3)
             dirs = d_chunk.unsqueeze(1).expand(-1, num_samples, -1).reshape(-1, 3)
             colors, dens = query_model(model, pos, dirs, near, far)
             colors = colors.reshape(o_chunk.shape[0], num_samples, 3)

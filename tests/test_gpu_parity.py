@@ -1050,6 +1050,45 @@ def test_posenc_backward_vs_torch(D, L):
 
 
 @pytest.mark.parametrize("tag", ["nerf", "siren"])
+def test_render_gradients_wrt_rays_vs_oracle(tag):
+    """render_nerf is transparent to autograd in rays_o / rays_d in the reference (rendering.py:59-62,223: positions are
+    tensor expressions of the rays).  Here such a call leaves the fused kernels for differentiable positions + the
+    layer-wise model kernels + the compositing kernel: rgb, the ray gradients and the parameter gradients against the
+    oracle's autograd, on rays whose samples keep 3e-6 from every ReLU kink."""
+    from nerf.rendering import render_nerf
+    model, params = make_model(tag)
+    fwd = oracle_fwd(tag)
+    R, S = 48, 40
+    o, d = rays(3 * R, 301)
+    u = torch.rand(S, generator=torch.Generator().manual_seed(302))
+    with torch.no_grad():
+        t = O.stratified_t(2.0, 6.0, S, u)
+        pn = O.normalize_positions(O.sample_positions(o, d, t), 2.0, 6.0).reshape(-1, 3)
+        _, _, acts = fwd(params, pn, d[:, None, :].expand(-1, S, -1).reshape(-1, 3), return_acts=True)
+        keep = (O.relu_kink_distance(acts).reshape(-1, S) > 3e-6).all(dim=1)
+    o, d = o[keep][:R].contiguous(), d[keep][:R].contiguous()
+    assert o.shape[0] == R
+    w = torch.randn(R, 3, generator=torch.Generator().manual_seed(303))
+    for p in params.values():
+        p.requires_grad_(True)
+    o_ref, d_ref = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    ref = O.render(lambda x, v: fwd(params, x, v), o_ref, d_ref, 2.0, 6.0, S, [u])
+    (ref * w).sum().backward()
+    o_g, d_g = o.to(DEV).requires_grad_(True), d.to(DEV).requires_grad_(True)
+    rgb = render_nerf(model, o_g, d_g, 2.0, 6.0, num_samples=S, device=DEV, u=[u.to(DEV)])
+    (rgb * w.to(DEV)).sum().backward()
+    assert rel(rgb, ref) < RTOL
+    assert rel(o_g.grad, o_ref.grad) < RTOL and rel(d_g.grad, d_ref.grad) < RTOL, (rel(o_g.grad, o_ref.grad), rel(d_g.grad, d_ref.grad))
+    assert float(o_ref.grad.abs().max()) > 0 and float(d_ref.grad.abs().max()) > 0
+    for (n, p), pr in zip(model.named_parameters(), params.values()):
+        assert rel(p.grad, pr.grad) < RTOL, (n, rel(p.grad, pr.grad))
+    # the same call without ray gradients stays on the fused kernels and renders the same image
+    with torch.no_grad():
+        fused = render_nerf(model, o.to(DEV), d.to(DEV), 2.0, 6.0, num_samples=S, device=DEV, u=[u.to(DEV)])
+    assert rel(fused, rgb) < RTOL        # two fp32 implementations of the same network (measured 1.1e-6)
+
+
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
 def test_model_input_gradients_vs_oracle(tag):
     """Model.forward is differentiable in points and directions in the reference (models.py:62-75, :185-203);
     here such calls take the layer-wise kernels.  Samples on a ReLU kink are dropped as elsewhere."""
