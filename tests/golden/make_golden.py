@@ -17,6 +17,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+# NERF_GOLDEN_OUT redirects the output (tests/test_oracle_golden.py's "live" source regenerates the vectors on the
+# host it runs on, into a temporary directory, and holds the oracle to them bit for bit).
+OUT = os.environ.get("NERF_GOLDEN_OUT", HERE)
 sys.path.insert(0, "/root/reference")
 sys.path.insert(0, ROOT)
 
@@ -40,7 +43,7 @@ def sym(n, stream, scale=1.0):
 
 def save(name, **kw):
     out = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in kw.items()}
-    np.savez_compressed(os.path.join(HERE, name), **out)
+    np.savez_compressed(os.path.join(OUT, name), **out)
     print(name, {k: v.shape for k, v in out.items()})
 
 
