@@ -350,17 +350,21 @@ __device__ __forceinline__ void fwd_epilogue(float* act, f32x16 (&acc)[MT][NT], 
                 const int row = acc_row(mi, g, lane);
                 float v = acc[mi][ni][g];
                 if constexpr (ACT == ACT_RELU) {
-                    // max(v, 0) as ONE instruction: fmaxf (and every intrinsic the compiler folds back into it) puts a
-                    // canonicalising v_max_f32 v, v, v in front, and VALU instructions are matrix-pipe time here
-                    asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(v));
+                    // ReLU layers arrive NEGATED: their weight image and bias are packed as 0 - w (nerf_mlp_pack), so
+                    // the accumulator holds n = -(W x + b) exactly (rounding is symmetric) and the decision bit
+                    // "pre-activation > 0" IS n's sign bit -- n = -0 cannot arise from a sum that starts at a bias packed
+                    // as 0 - b, and an exactly cancelling sum gives +0 -- shifted into the mask word as it is: element
+                    // e = (mi*NT + ni)*16 + g ends up at bit 31 - (e & 31) of word e >> 5.  One instruction per element
+                    // for the mask and one for max(-n, 0) (written as the instruction: fmaxf, and every intrinsic the
+                    // compiler folds back into it, puts a canonicalising v_max_f32 v, v, v in front); vector instructions
+                    // are matrix-pipe time here.
                     if constexpr (NT == 2) {
-                        // 0 - v is negative exactly when v > 0 (and +0 for both zeros): its sign bit is shifted into
-                        // the word, so element e = (mi*NT + ni)*16 + g ends up at bit 31 - (e & 31) of word e >> 5
                         const int bit = (mi * NT + ni) * 16 + g;
-                        const unsigned t = __builtin_bit_cast(unsigned, 0.0f - v);
+                        const unsigned t = __builtin_bit_cast(unsigned, v);
                         if (bit < 32) mlo = __builtin_amdgcn_alignbit(mlo, t, 31);
                         else mhi = __builtin_amdgcn_alignbit(mhi, t, 31);
                     }
+                    asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v) : "v"(v));
                 }
                 act[row * LDA + col] = v;
             }
@@ -445,6 +449,68 @@ __device__ __forceinline__ void encode_axis(float* dst, int axis, float x, int j
         dst[3 + 6 * j + axis] = s;
         dst[3 + 6 * j + 3 + axis] = c;
         scale *= 2.0f;
+    }
+}
+
+// Table form of the same encoding for 64-row tiles (four threads per sample), used when every argument of the tile
+// stays inside the table form's range (|2^(L-1) x| <= 9.9e4, decided once per tile by the caller).  Threads 0..2 of a
+// sample own one axis each and the frequency pairs (2i, 2i+1), i < ROUNDS; for L = 10 thread 3 owns the fifth pair
+// (frequencies 8, 9) of all three axes, one axis per round -- 4 rounds of one value pair per thread instead of 10
+// full-range evaluations on three threads out of four.  Per value pair: 13 packed operations + 2 table-offset shifts
+// (sincos_tab_issue / sincos_tab_finish) against ~50 vector instructions per frequency of the full-range form, and
+// vector instructions are matrix-pipe time in these kernels.  The results stay in registers (EncCache) so that the
+// second use of the position encoding (the skip layer) only writes them to LDS again.
+// The sine/cosine table must sit in the first 2 KiB of LDS (load_sincos_table).
+template <int L>
+struct EncCache {
+    static constexpr int ROUNDS = L == 10 ? 4 : L / 2;
+    f32x2 sn[ROUNDS], cs[ROUNDS];
+    float x;   // the thread's own coordinate (threads 0..2)
+};
+template <int L>
+__device__ __forceinline__ bool enc_round_active(int q, int i) { return q < 3 || (L == 10 && i < 3); }
+
+// xs: the sample's three coordinates in LDS (xin row + 0 for positions, + 3 for directions)
+template <int L>
+__device__ __forceinline__ void enc_compute(const float* xs, int q, EncCache<L>& c) {
+    static_assert(TPS == 4 && (L == 10 || L == 4), "four threads per sample");
+    constexpr int R = EncCache<L>::ROUNDS;
+    const bool extra = q == 3;
+    c.x = xs[extra ? 0 : q];
+    SinCosPair pr[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        // powers of two: the products are exact, as mul_rn(2^j, x) in the full-range form
+        const float xv = (L == 10 && extra) ? xs[i < 3 ? i : 0] : c.x;
+        const float scale = (L == 10 && extra) ? 256.0f : (float)(1 << (2 * i));
+        const float a0 = mul_rn(scale, xv);
+        sincos_tab_issue((f32x2){a0, mul_rn(2.0f, a0)}, pr[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) sincos_tab_finish(pr[i], c.sn[i], c.cs[i]);
+}
+
+// writes the cached encoding into the sample's tile row (column layout of nerf/encoding.py: x, then per frequency
+// j the three sines at 3 + 6j and the three cosines at 6 + 6j); thread 3 also zeroes the padding columns
+template <int L>
+__device__ __forceinline__ void enc_store(float* row, int q, const EncCache<L>& c) {
+    constexpr int R = EncCache<L>::ROUNDS;
+    const bool extra = q == 3;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (enc_round_active<L>(q, i)) {
+            // frequency pair p = i (threads 0..2, axis q) or p = 4 (thread 3, axis i): column 3 + 12 p + axis
+            float* d = row + (extra ? 48 + i : 12 * i + q);
+            d[3] = c.sn[i][0];
+            d[6] = c.cs[i][0];
+            d[9] = c.sn[i][1];
+            d[12] = c.cs[i][1];
+        }
+    }
+    if (!extra) row[q] = c.x;
+    else {
+#pragma unroll
+        for (int col = 3 + 6 * L; col < ((3 + 6 * L + 7) & ~7); ++col) row[col] = 0.0f;
     }
 }
 

@@ -17,6 +17,7 @@ struct PackJob {
     int sn, sk;        // strides of the image's N and K index in the source
     int N, K, KB;      // KB == 0: plain copy of N floats
     unsigned dst_off;  // float offset inside the packed image
+    int neg;           // store 0 - value: the layers whose epilogue is a ReLU run negated (fwd_epilogue)
 };
 constexpr int kMaxPackJobs = 48;
 struct PackArgs {
@@ -31,46 +32,48 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     const float* __restrict__ src = a.src[j.tensor] + j.src_off;
     float* __restrict__ dst = a.dst + j.dst_off;
     if (j.KB == 0) {
-        for (int i = blockIdx.y * 256 + threadIdx.x; i < j.N; i += gridDim.y * 256) dst[i] = src[i];
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < j.N; i += gridDim.y * 256) dst[i] = j.neg ? 0.0f - src[i] : src[i];
         return;
     }
     const int total = j.KB * j.N * 8;
     for (int i = blockIdx.y * 256 + threadIdx.x; i < total; i += gridDim.y * 256) {
         const int jj = i & 7, n = (i >> 3) % j.N, kb = (i >> 3) / j.N;
         const int k = kb * 8 + jj;
-        dst[i] = (k < j.K) ? src[(size_t)n * j.sn + (size_t)k * j.sk] : 0.0f;
+        const float v = (k < j.K) ? src[(size_t)n * j.sn + (size_t)k * j.sk] : 0.0f;
+        dst[i] = j.neg ? 0.0f - v : v;     // (0 - v, not -v: zero weights, biases and the padding stay +0)
     }
 }
 
-void add_fwd(PackArgs& a, int tensor, int ld, int col0, int row0, int N, int K, size_t dst) {
+void add_fwd(PackArgs& a, int tensor, int ld, int col0, int row0, int N, int K, size_t dst, bool neg = false) {
     // forward image of rows row0..row0+N, columns col0..col0+K of a [*, ld] weight
-    a.jobs[a.njobs++] = PackJob{tensor, row0 * ld + col0, ld, 1, N, K, (K + 7) / 8, (unsigned)dst};
+    a.jobs[a.njobs++] = PackJob{tensor, row0 * ld + col0, ld, 1, N, K, (K + 7) / 8, (unsigned)dst, neg};
 }
 void add_bwd(PackArgs& a, int tensor, int ld, int col0, int row0, int Nin, int Kout, size_t dst) {
     // transposed image: reduce over rows row0..row0+Kout, image columns = weight columns col0..col0+Nin
-    a.jobs[a.njobs++] = PackJob{tensor, row0 * ld + col0, 1, ld, Nin, Kout, (Kout + 7) / 8, (unsigned)dst};
+    a.jobs[a.njobs++] = PackJob{tensor, row0 * ld + col0, 1, ld, Nin, Kout, (Kout + 7) / 8, (unsigned)dst, 0};
 }
-void add_copy(PackArgs& a, int tensor, int off, int count, size_t dst) {
-    a.jobs[a.njobs++] = PackJob{tensor, off, 0, 0, count, 0, 0, (unsigned)dst};
+void add_copy(PackArgs& a, int tensor, int off, int count, size_t dst, bool neg = false) {
+    a.jobs[a.njobs++] = PackJob{tensor, off, 0, 0, count, 0, 0, (unsigned)dst, neg};
 }
 
 void build_nerf_jobs(PackArgs& a) {
     using namespace lay;
     using namespace lay::nerf;
-    add_fwd(a, 0, PE, 0, 0, H, PE, F_L0);
-    for (int l = 1; l <= 4; ++l) add_fwd(a, 2 * l, H, 0, 0, H, H, F_L1 + (size_t)(l - 1) * img(H, H));
-    add_fwd(a, 10, H + PE, 0, 0, H, H, F_L5A);
-    add_fwd(a, 10, H + PE, H, 0, H, PE, F_L5B);
-    for (int l = 6; l <= 8; ++l) add_fwd(a, 2 * l, H, 0, 0, H, H, F_L6 + (size_t)(l - 6) * img(H, H));
+    // the ten ReLU layers (L0..L8 and rgb_head.0) are packed negated, weights and biases: see fwd_epilogue
+    add_fwd(a, 0, PE, 0, 0, H, PE, F_L0, true);
+    for (int l = 1; l <= 4; ++l) add_fwd(a, 2 * l, H, 0, 0, H, H, F_L1 + (size_t)(l - 1) * img(H, H), true);
+    add_fwd(a, 10, H + PE, 0, 0, H, H, F_L5A, true);
+    add_fwd(a, 10, H + PE, H, 0, H, PE, F_L5B, true);
+    for (int l = 6; l <= 8; ++l) add_fwd(a, 2 * l, H, 0, 0, H, H, F_L6 + (size_t)(l - 6) * img(H, H), true);
     add_fwd(a, 18, H, 0, 0, H, H, F_L9);
-    add_fwd(a, 20, H + DE, 0, 0, HH, H, F_L10A);
-    add_fwd(a, 20, H + DE, H, 0, HH, DE, F_L10B);
+    add_fwd(a, 20, H + DE, 0, 0, HH, H, F_L10A, true);
+    add_fwd(a, 20, H + DE, H, 0, HH, DE, F_L10B, true);
     add_copy(a, 18, H * H, H, SIGW);
     add_copy(a, 22, 0, 3 * HH, W11);
-    for (int l = 0; l <= 8; ++l) add_copy(a, 2 * l + 1, 0, H, BIAS + (size_t)l * H);
+    for (int l = 0; l <= 8; ++l) add_copy(a, 2 * l + 1, 0, H, BIAS + (size_t)l * H, true);
     add_copy(a, 19, 0, H, BIAS + 9 * (size_t)H);
     add_copy(a, 19, H, 1, BIAS_SIG);
-    add_copy(a, 21, 0, HH, BIAS10);
+    add_copy(a, 21, 0, HH, BIAS10, true);
     add_copy(a, 23, 0, 3, BIAS11);
     add_bwd(a, 20, H + DE, 0, 0, H, HH, D10);
     add_bwd(a, 18, H, 0, 0, H, H, d_img(9));
@@ -173,7 +176,8 @@ struct FwdArgs {
 
 constexpr int XIN_FLOATS = TR * 8;
 constexpr int FWD_LDS_BYTES = (ACT_FLOATS + XIN_FLOATS + TR) * 4;
-constexpr int SIREN_FWD_LDS_BYTES = FWD_LDS_BYTES + SINCOS_TAB_FLOATS * 4;   // + the sine/cosine table
+constexpr int TAB_FWD_LDS_BYTES = FWD_LDS_BYTES + SINCOS_TAB_FLOATS * 4;     // + the sine/cosine table (both networks)
+constexpr int SIREN_FWD_LDS_BYTES = TAB_FWD_LDS_BYTES;
 
 __device__ __forceinline__ float norm_coord(float p, float nearf, float spanf) {
 #pragma clang fp contract(off)  // each operation rounded on its own, as the reference's tensor ops are
@@ -208,7 +212,11 @@ __device__ __forceinline__ void load_inputs(const FwdArgs& a, size_t m0, float* 
         float big = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fabsf(x[2]));
 #pragma unroll
         for (int off = TR / 2; off >= 1; off >>= 1) big = fmaxf(big, __shfl_xor(big, off, TR));
-        if (tid == 0) xin[6] = big;
+        // xin[7]: the same for the direction components (the table form of the direction encoding has a range too)
+        float bigd = fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fabsf(d[2]));
+#pragma unroll
+        for (int off = TR / 2; off >= 1; off >>= 1) bigd = fmaxf(bigd, __shfl_xor(bigd, off, TR));
+        if (tid == 0) { xin[6] = big; xin[7] = bigd; }
     }
 }
 
@@ -231,6 +239,14 @@ __device__ __forceinline__ void encode_de(float* act, const float* xin, int tid)
 #pragma unroll
         for (int c = lay::DE; c < lay::DE_P; ++c) act[smp * LDA + c] = 0.0f;
     }
+}
+
+// Position / direction encoding of the tile: the table form when the tile's arguments allow it (tile-uniform decision from
+// the largest |coordinate| that load_inputs left in xin[6] / xin[7]; NaN and infinite coordinates fail the comparison or,
+// swallowed by the maximum, give NaN on either path), the full-range form otherwise.  `fast` is wave-uniform.
+__device__ __forceinline__ bool enc_fast(const float* xin, int slot, float top_scale) {
+    const float big = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xin[slot])));
+    return TPS == 4 && big * top_scale <= 9.9e4f;
 }
 
 // dot of each tile row (first 256 columns) with a 256-vector; TPS threads per sample
@@ -324,8 +340,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
     using namespace lay;
     using namespace lay::nerf;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* act = smem;
-    float* xin = smem + ACT_FLOATS;
+    float* act = smem + SINCOS_TAB_FLOATS;   // the sine/cosine table of the encodings occupies the first 2 KiB
+    float* xin = act + ACT_FLOATS;
     float* sraw_s = xin + XIN_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -349,10 +365,19 @@ __global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
     }
 #endif
     DIAG_STAMP(0);
+    load_sincos_table(smem, tid);
     load_inputs(a, m0, xin, tid);
     __syncthreads();
     DIAG_STAMP(1);
-    encode_pe(act, xin, tid);
+    // position encoding: computed once, kept in registers for its second use in the skip layer
+    const bool pe_fast = enc_fast(xin, 6, 512.0f);
+    EncCache<10> pec;
+    if (pe_fast) {
+        enc_compute<10>(xin + (tid / TPS) * 8, tid % TPS, pec);
+        enc_store<10>(act + (tid / TPS) * LDA, tid % TPS, pec);
+    } else {
+        encode_pe(act, xin, tid);
+    }
     __syncthreads();
     DIAG_STAMP(2);
 
@@ -381,7 +406,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
         if constexpr (TRAIN) *mskp(4) = mask;
         __syncthreads();
         DIAG_STAMP(8);
-        encode_pe(act, xin, tid);
+        if (pe_fast) enc_store<10>(act + (tid / TPS) * LDA, tid % TPS, pec);
+        else encode_pe(act, xin, tid);
         __syncthreads();
         DIAG_STAMP(9);
         mma_layer<2>(act, pk + F_L5B, H, PE_P / 8, ncol0, lane, acc);
@@ -426,7 +452,13 @@ __global__ __launch_bounds__(256, WG_PER_CU) void nerf_fwd_kernel(FwdArgs a) {
         mma_layer<1, TRAIN ? H : 0, ACC_BIAS>(act, pk + F_L10A, HH, H / 8, nc, lane, acc, wsp(WS_F, H), tid, pk + BIAS10);
         __syncthreads();
         DIAG_STAMP(15);
-        encode_de(act, xin, tid);
+        if (enc_fast(xin, 7, 8.0f)) {
+            EncCache<4> dec;
+            enc_compute<4>(xin + (tid / TPS) * 8 + 3, tid % TPS, dec);
+            enc_store<4>(act + (tid / TPS) * LDA, tid % TPS, dec);
+        } else {
+            encode_de(act, xin, tid);
+        }
         __syncthreads();
         DIAG_STAMP(16);
         mma_layer<1, TRAIN ? DE_P : 0>(act, pk + F_L10B, HH, DE_P / 8, nc, lane, acc, wsp(WS_DE, DE_P), tid);
@@ -599,14 +631,14 @@ extern "C" int nerf_mlp_fwd(int model, const float* packed, int64_t M, const flo
     int rc;
     if (model == NERF_MODEL_NERF) {
         if (workspace) {
-            if ((rc = nerf_set_lds(nerf_fwd_kernel<true>, FWD_LDS_BYTES))) return rc;
-            nerf_fwd_kernel<true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+            if ((rc = nerf_set_lds(nerf_fwd_kernel<true>, TAB_FWD_LDS_BYTES))) return rc;
+            nerf_fwd_kernel<true><<<(unsigned)tiles, 256, TAB_FWD_LDS_BYTES, st>>>(a);
         } else if (colors) {
-            if ((rc = nerf_set_lds(nerf_fwd_kernel<false>, FWD_LDS_BYTES))) return rc;
-            nerf_fwd_kernel<false><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+            if ((rc = nerf_set_lds(nerf_fwd_kernel<false>, TAB_FWD_LDS_BYTES))) return rc;
+            nerf_fwd_kernel<false><<<(unsigned)tiles, 256, TAB_FWD_LDS_BYTES, st>>>(a);
         } else {
-            if ((rc = nerf_set_lds(nerf_fwd_kernel<false, true>, FWD_LDS_BYTES))) return rc;
-            nerf_fwd_kernel<false, true><<<(unsigned)tiles, 256, FWD_LDS_BYTES, st>>>(a);
+            if ((rc = nerf_set_lds(nerf_fwd_kernel<false, true>, TAB_FWD_LDS_BYTES))) return rc;
+            nerf_fwd_kernel<false, true><<<(unsigned)tiles, 256, TAB_FWD_LDS_BYTES, st>>>(a);
         }
     } else {
         if (workspace) {
