@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="bf16 / bf16x3: the opt-in inference modes on the bf16 matrix pipe (--mode infer, nerf only; bf16x3 = "
                          "three-term split at fp32 accuracy); never the default metric")
+    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="opt-in (never the default line): forward and data gradient of a training step on the bf16 matrix "
+                         "pipe at fp32 accuracy (three bf16 terms per operand); the weight gradient stays on fp32 MFMA; NeRF only")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the multi-rank code path on a box with a single GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -239,6 +242,11 @@ def main():
             raise SystemExit(f"--precision {args.precision} is an inference-only mode: add --mode infer")
         for m in models:
             m.set_inference_precision(args.precision)
+    if args.train_precision != "fp32":
+        if args.mode != "train":
+            raise SystemExit("--train-precision applies to --mode train")
+        for m in models:
+            m.set_training_precision(args.train_precision)
     flat = parallel.FlatParameters(torch.nn.ModuleList(models))   # one bucket, one all-reduce, one Adam launch
     flat.broadcast_parameters(0)
     opt = parallel.FusedAdam(flat, lr=5e-4)
@@ -326,6 +334,9 @@ def main():
         if args.mode == "train":
             specs = [("mlp_fwd_train", fl["fwd"], "fused sample+encode+MLP forward (training, stores activations)"),
                      ("mlp_bwd_data", fl["dgrad"], "fused data-gradient chain"),
+                     ("mlp_fwd_train_x3", 6 * fl["fwd"], "bf16x3 opt-in: the training forward with every fp32 operand as three bf16 "
+                                                         "terms; matrix-pipe flops = 6 term products per product of the fp32 algorithm"),
+                     ("mlp_bwd_data_x3", 6 * fl["dgrad"], "bf16x3 opt-in: the data-gradient chain, same arithmetic"),
                      ("mlp_bwd_weights", fl["wgrad"], "per-layer weight-gradient GEMMs + one reduction (launch group)")]
         else:
             specs = [("mlp_fwd_infer", fl["fwd"], "fused sample+encode+MLP forward (inference)"),
@@ -368,7 +379,7 @@ def main():
         kernels = kernel_table(tm_timed, args.steps)
         if overlapped:
             for name, k in kernels.items():
-                if name.split("@")[0] != "mlp_fwd_train":
+                if name.split("@")[0] not in ("mlp_fwd_train", "mlp_fwd_train_x3"):
                     k["concurrent"] = True          # bracket includes the other stream's kernels
         # The roofline object describes ONE kernel over all its launches of the timed region (what a rocprofv3
         # --kernel-trace --stats average of the same command shows): the fused forward, which runs alone on the
@@ -389,7 +400,7 @@ def main():
             ach = m["flop"] / m["ms"] / 1e9
             samples_per_launch = m["flop"] / m["n"] / m["per_sample"]
             tb, tb_files = pmc_traffic_per_sample(args.model, dom)
-            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom else PEAK_F32_MFMA_TFLOPS
+            peak = PEAK_BF16_MFMA_TFLOPS if ("bf16" in dom or dom.endswith("_x3")) else PEAK_F32_MFMA_TFLOPS
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                     "frac": ach / peak, "traffic": tb * samples_per_launch if tb else None,
                     "traffic_unit": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) per sample of the rocprofv3 --pmc "
@@ -406,20 +417,23 @@ def main():
                             + (f", the {args.coarse} coarse ones density only)" if hier else ")")),
             "value": world * B * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3 (forward, data gradient) + f32 (weight gradient)" if args.train_precision == "bf16x3"
+            else {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
             "config": {"workload": f"lego-shaped synthetic {args.res}x{args.res} scene, {B} rays/GPU/step, "
                                    + (f"{args.coarse} coarse + ({args.coarse}+{args.fine}) fine = {S} MLP evaluations/ray, "
                                       f"coarse+fine {args.model} MLPs" if hier else
                                       f"{S} samples/ray single pass, one {args.model} MLP")
                                    + {"fp32": " (fp32 MFMA)", "bf16": " (bf16 MFMA, fp32 accumulate)",
-                                      "bf16x3": " (fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate)"}[args.precision] + f", {args.mode}", "network": args.model, "sampling": args.sampling,
+                                      "bf16x3": " (fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate)"}[args.precision]
+                                   + (" -- opt-in training mode: forward and data gradient as three bf16 terms per operand, weight gradient fp32 MFMA"
+                                      if args.train_precision == "bf16x3" else "") + f", {args.mode}", "network": args.model, "sampling": args.sampling,
                        "rays_per_gpu": B, "rays_per_step": B * world, "mlp_evals_per_ray": S,
                        "parallelism": f"dp{world} ray-sharded, flat-bucket RCCL all-reduce" if world > 1 else "single GPU"},
             "roofline": roof,
             "kernels": kernels,
             "kernels_serialized": kernel_table(tm_serial, 2) if tm_serial else None,
             "step_mfma_frac": (total_flop / (ms_step * 1e-3) / 1e12)
-                              / (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS),
+                              / (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" and args.train_precision == "fp32" else PEAK_BF16_MFMA_TFLOPS),
             "final_value": final,
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":

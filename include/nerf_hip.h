@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 9
+#define NERF_ABI_VERSION 10
 
 #define NERF_OK 0
 #define NERF_E_ARG (-1)      /* bad shape / size / unsupported configuration */
@@ -177,6 +177,24 @@ int nerf_mlp_bwd_data(int model, const float* packed, int64_t M, const float* dc
                       const float* colors, const float* fwd_workspace, float* bwd_workspace, void* stream);
 int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
                          int accumulate, void* stream);
+
+/* ---- opt-in three-term TRAINING mode "bf16x3" (NERF_MODEL_NERF; no counterpart in the reference, whose
+ * train step, train.py:166-183, is fp32 throughout) ------------------------------------------------------
+ * nerf_mlp_fwd with a workspace, and nerf_mlp_bwd_data, on the bf16 matrix pipe with the arithmetic of the bf16x3
+ * inference mode above (three bf16 terms per fp32 operand, six exact term products per product, fp32
+ * accumulation): same arguments, same workspaces, results within fp32 accumulation rounding of the fp32 kernels'
+ * (same 1e-5 bar, gradients included).  `packed` is an image of nerf_mlp_packed_x3_floats(model) FLOATS built by
+ * nerf_mlp_pack_x3: the fp32 image of nerf_mlp_pack (so the same pointer also serves nerf_mlp_fwd without a
+ * workspace) followed by the three-term planes of every dense layer, forward and transposed.  A workspace written
+ * by nerf_mlp_fwd_x3 must be read by nerf_mlp_bwd_data_x3 (its ReLU mask words follow this mode's accumulator
+ * columns); nerf_mlp_bwd_weights then runs unchanged on both workspaces. */
+size_t nerf_mlp_packed_x3_floats(int model);                   /* 0 for a model without this mode */
+int nerf_mlp_pack_x3(int model, const float* const* params, float* packed, void* stream);
+int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const float* points, const float* dirs,
+                    const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near,
+                    double far, float* colors, float* density, float* workspace, void* stream);
+int nerf_mlp_bwd_data_x3(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
+                         const float* colors, const float* fwd_workspace, float* bwd_workspace, void* stream);
 
 /* ---- layer-wise dense path for the other architectures the reference's constructors accept
  * (nerf/models.py:18-60 NeRF(pos_encoding_dim, dir_encoding_dim, hidden_dim), :148-183 Siren(...)):

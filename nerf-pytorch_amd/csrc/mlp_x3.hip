@@ -1,0 +1,735 @@
+// Opt-in TRAINING kernels of the NeRF MLP (nerf/models.py:62-75 and what autograd derives for it, train.py:181) on the
+// bf16 matrix pipe at fp32 accuracy ("bf16x3"): forward with the activation workspace, and the data-gradient chain.
+// The default training path stays the fp32 MFMA kernels of mlp_fwd.hip / mlp_bwd.hip; the weight-gradient GEMMs
+// (nerf_mlp_bwd_weights) are shared by both and stay on fp32 MFMA.
+//
+// Arithmetic (the three-term expansion of mlp_bf16.hip): every fp32 operand is the exact sum of three bf16 terms,
+// x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); a product of two operands is formed from
+// the six term products that reach fp32 precision, w*x ~= w0 x0 + w0 x1 + w0 x2 + w1 x0 + w1 x1 + w2 x0, each exact in
+// the MFMA's fp32 accumulator -- six v_mfma_f32_32x32x16_bf16 (32 cycles per 16 k) in place of eight
+// v_mfma_f32_32x32x2_f32 (64 cycles per 2 k): 0.375 of the matrix-pipe time, the rounding of an fp32 accumulation
+// and nothing else.
+//
+// Structure: the fp32 tile kernels' (same 64-sample tile, same wave -> output-column split, same accumulator register
+// map, same workspace), so that masks, activations and layer gradients land where nerf_mlp_bwd_weights expects them.
+// What differs:
+//   * the layer input lives in LDS as THREE bf16 planes [64][264] (one per term) instead of one fp32 tile; the
+//     epilogue splits every output value once (13 vector instructions per value pair) and writes the three terms;
+//   * weights come from three bf16 images per layer (k-steps of 16: one 16-byte load per lane, plane and k-step);
+//   * a wave's two 32-column accumulator tiles interleave their columns (tile ni holds columns ncol0 + 2 r + ni),
+//     so that a lane owns two ADJACENT columns of every row: one packed bf16 pair per LDS write, one 8-byte store per
+//     row for the fp32 copy of the tile that goes to the workspace straight from the registers (the fp32 kernels
+//     copy it from their fp32 LDS tile inside the next MFMA loop; there is no fp32 tile here);
+//   * 101 KiB of planes: one workgroup per CU, one wave per SIMD.
+#include "mlp_device.h"
+
+using namespace dev;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+static_assert(TR == 64 && MT == 2 && TPS == 4, "the bf16x3 training kernels are written for 64-row tiles");
+
+// ---- LDS ----------------------------------------------------------------------------------------------
+constexpr int LDPB = 528;                        // bytes per plane row: 256 bf16 + 16 bytes (bank spread of the A reads)
+constexpr int PLANE_BYTES = TR * LDPB;
+constexpr int PLANES_BYTES = 3 * PLANE_BYTES;    // 101,376
+constexpr int X3_XIN_FLOATS = TR * 8;
+// table | planes | xin | sraw
+constexpr int X3_FWD_LDS_BYTES = SINCOS_TAB_FLOATS * 4 + PLANES_BYTES + X3_XIN_FLOATS * 4 + TR * 4;
+constexpr int X3_BWD_LDS_BYTES = PLANES_BYTES + TR * 4;
+// fp32 views of the plane area while no layer input lives there: the 128-wide rgb hidden tile [64][132]
+constexpr int LDG = 132;
+static_assert(TR * LDG * 4 <= PLANES_BYTES, "fp32 view of the plane area");
+
+// ---- bf16x3 images (units: bf16 elements) ---------------------------------------------------------------
+// One dense layer, K padded to 16: three planes of [K/16][N][16] bf16; element (ks, pos, h, j) of a plane is term p of
+// W[col(pos)][16 ks + 8 h + j].  col(pos) = pos for the 128-wide layer; for 256-wide outputs the two 32-column tiles
+// of a wave interleave: position 64 w + 32 ni + r holds column 64 w + 2 r + ni.
+namespace x3 {
+using namespace lay;
+constexpr size_t elems(int Kp, int N) { return (size_t)3 * Kp * N; }
+constexpr size_t F_L0 = 0;
+constexpr size_t F_L1 = F_L0 + elems(PE_P, H);
+constexpr size_t F_L5A = F_L1 + 4 * elems(H, H);
+constexpr size_t F_L5B = F_L5A + elems(H, H);
+constexpr size_t F_L6 = F_L5B + elems(PE_P, H);
+constexpr size_t F_L9 = F_L6 + 3 * elems(H, H);
+constexpr size_t F_L10A = F_L9 + elems(H, H);
+constexpr size_t F_L10B = F_L10A + elems(H, HH);
+constexpr size_t D10 = F_L10B + elems(DE_P, HH);
+constexpr size_t D9 = D10 + elems(HH, H);
+constexpr size_t TOTAL = D9 + 9 * elems(H, H);
+constexpr size_t d_img(int layer) { return D9 + (size_t)(9 - layer) * elems(H, H); }   // layer 1..9
+static_assert(TOTAL % 8 == 0 && lay::nerf::PACKED_FLOATS % 4 == 0, "16-byte pieces");
+constexpr size_t TOTAL_FLOATS = TOTAL / 2;
+}  // namespace x3
+
+struct X3Job {
+    int tensor, src_off, sn, sk;   // W element (n, k) = src[tensor][src_off + n*sn + k*sk]
+    int N, K, Kp;
+    int neg, interleave;
+    size_t dst;                    // bf16 offset of the layer's first plane
+};
+constexpr int kMaxX3Jobs = 24;
+struct X3PackArgs {
+    const float* src[NERF_NUM_PARAM_TENSORS];
+    __bf16* dst;
+    int njobs;
+    X3Job jobs[kMaxX3Jobs];
+};
+
+__device__ __forceinline__ __bf16 term_of(float x, int plane) {
+    __bf16 t = (__bf16)x;
+    for (int i = 0; i < plane; ++i) {
+        x -= (float)t;      // exact
+        t = (__bf16)x;
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(256) void pack_x3_kernel(X3PackArgs a) {
+    const X3Job j = a.jobs[blockIdx.x];
+    const float* __restrict__ src = a.src[j.tensor] + j.src_off;
+    const int pieces_per_plane = j.Kp * j.N / 8;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < 3 * pieces_per_plane; i += gridDim.y * 256) {
+        const int p = i / pieces_per_plane, q = i - p * pieces_per_plane;
+        const int h = q & 1, pos = (q >> 1) % j.N, ks = (q >> 1) / j.N;
+        const int n = j.interleave ? (pos & ~63) + 2 * (pos & 31) + ((pos >> 5) & 1) : pos;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * ks + 8 * h + e;
+            float w = (k < j.K) ? src[(size_t)n * j.sn + (size_t)k * j.sk] : 0.0f;
+            if (j.neg) w = 0.0f - w;     // ReLU layers run negated (fwd_epilogue of mlp_device.h); terms of -w are minus the terms of w
+            v[e] = term_of(w, p);
+        }
+        *reinterpret_cast<bf16x8*>(a.dst + j.dst + (size_t)p * j.Kp * j.N + (size_t)q * 8) = v;
+    }
+}
+
+void x3_fwd_job(X3PackArgs& a, int tensor, int ld, int col0, int N, int K, size_t dst, bool neg, bool inter) {
+    a.jobs[a.njobs++] = X3Job{tensor, col0, ld, 1, N, K, (K + 15) / 16 * 16, neg, inter, dst};
+}
+void x3_bwd_job(X3PackArgs& a, int tensor, int ld, int Nin, int Kout, size_t dst) {
+    // transposed: reduce over the Kout output rows, image columns = the layer's first Nin input columns
+    a.jobs[a.njobs++] = X3Job{tensor, 0, 1, ld, Nin, Kout, (Kout + 15) / 16 * 16, 0, 1, dst};
+}
+
+// ---- K loop ---------------------------------------------------------------------------------------------
+// acc[mi][ni] (+)= sum over KS k-steps of the six term products of planes (LDS, rows 32 mi + r) and the three image
+// planes (global, position ncol0 + 32 ni + r).  Fully unrolled (KS is 2, 4, 8 or 16): fragment sets rotate by
+// compile-time index; the weight fragments of k-step ks + 2 and the activation fragments of ks + 1 are requested before
+// the 24 (NT = 2) MFMAs of k-step ks -- with one wave per SIMD nothing else hides the L2 latency.
+template <int NT, int KS, int INIT>
+__device__ __forceinline__ void mma_layer_x3(const unsigned char* planes, const __bf16* __restrict__ img, int N, int ncol0,
+                                             int lane, f32x16 (&acc)[MT][NT], const float* __restrict__ bias = nullptr) {
+    const int r = lane & 31, h = lane >> 5;
+    float bias_v[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        // the accumulator's column: interleaved for the two-tile layers (see the header of this file)
+        const int col = NT == 2 ? ncol0 + 2 * r + ni : ncol0 + r;
+        bias_v[ni] = (INIT == ACC_BIAS) ? bias[col] : 0.0f;
+    }
+    const int plane_elems = KS * 16 * N;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(img, (unsigned)(3 * plane_elems * 2));
+    const int b_voff = ((ncol0 + r) * 16 + 8 * h) * 2;
+    const unsigned char* a_ptr = planes + r * LDPB + 16 * h;
+    bf16x8 A[2][MT][3], B[3][NT][3];
+    auto load_b = [&](int ks, bf16x8 (&b)[NT][3]) {
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                b[ni][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                          rsrc, b_voff + ni * 32 * 32, (p * plane_elems + ks * N * 16) * 2, 0));
+    };
+    auto load_a = [&](int ks, bf16x8 (&a)[MT][3]) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                a[mi][p] = *reinterpret_cast<const bf16x8*>(a_ptr + p * PLANE_BYTES + mi * 32 * LDPB + ks * 32);
+    };
+    load_b(0, B[0]);
+    if constexpr (KS > 1) load_b(1, B[1]);
+    load_a(0, A[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 2 < KS) load_b(ks + 2, B[(ks + 2) % 3]);
+        if (ks + 1 < KS) load_a(ks + 1, A[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 (&a)[MT][3] = A[ks & 1];
+        const bf16x8 (&b)[NT][3] = B[ks % 3];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                f32x16 c;
+                if (ks == 0 && INIT == ACC_ZERO) c = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                else if (ks == 0 && INIT == ACC_BIAS) c = splat16(bias_v[ni]);
+                else c = acc[mi][ni];
+                // smallest terms first would not change what is exact: every product is exact, the sum rounds like fp32
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
+                acc[mi][ni] = c;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- splitting ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
+}
+// the three bf16 terms of a pair of floats, each as a packed pair (low half = first value)
+__device__ __forceinline__ void split2(float v0, float v1, unsigned (&w)[3]) {
+#pragma clang fp contract(off)
+    w[0] = pack2(v0, v1);
+#pragma unroll
+    for (int p = 1; p < 3; ++p) {
+        v0 -= __builtin_bit_cast(float, w[p - 1] << 16);           // exact
+        v1 -= __builtin_bit_cast(float, w[p - 1] & 0xffff0000u);
+        w[p] = pack2(v0, v1);
+    }
+}
+__device__ __forceinline__ void store_terms(unsigned char* planes, int byte_off, const unsigned (&w)[3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(planes + p * PLANE_BYTES + byte_off) = w[p];
+}
+// one value's three terms into (row, col) of the planes (the encodings, whose threads own scattered columns)
+__device__ __forceinline__ void store_value(unsigned char* planes, int row, int col, float v) {
+    unsigned w[3];
+    split2(v, 0.0f, w);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<unsigned short*>(planes + p * PLANE_BYTES + row * LDPB + col * 2) = (unsigned short)w[p];
+}
+
+// Epilogue of a 256-wide layer (two interleaved tiles per wave): activation, mask bits, the fp32 tile to the
+// workspace, the three terms to the planes.  Layers with a ReLU arrive negated (their images are packed as 0 - w): the
+// accumulator's sign bit is the decision "pre-activation > 0" (fwd_epilogue of mlp_device.h has the argument).
+//   MODE 0: forward, no activation          MODE 1: forward, ReLU of the negated accumulator, mask out
+//   MODE 2: backward, mask in               MODE 3: backward, rank-1 term (dsig[row] * sigw[col]) then mask in
+//   MODE 4: backward, nothing
+// gout: this tile's [64][256] fp32 rows in the workspace (NULL: not stored).  TO_PLANES false: the last layer of a chain.
+template <int MODE, bool TO_PLANES>
+__device__ __forceinline__ void x3_epilogue(unsigned char* planes, f32x16 (&acc)[MT][2], int ncol0, int lane,
+                                            float* __restrict__ gout, mask_t* mask_out, mask_t mask_in,
+                                            const float* dsig_lds, const float* __restrict__ sigw) {
+    const int r = lane & 31, h = lane >> 5;
+    const int col = ncol0 + 2 * r;
+    unsigned mlo = 0u, mhi = 0u;
+    const unsigned blo = (unsigned)mask_in, bhi = (unsigned)((unsigned long long)mask_in >> 32);
+    const __amdgpu_buffer_rsrc_t g_rsrc = make_rsrc(gout, (unsigned)(TR * lay::H * 4));
+    const int g_voff = (4 * h * lay::H + col) * 4;
+    f32x2 sw = {0.f, 0.f};
+    if constexpr (MODE == 3) sw = *reinterpret_cast<const f32x2*>(sigw + col);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int row0 = 32 * mi + (g & 3) + 8 * (g >> 2);      // + 4 h
+            float v[2] = {acc[mi][0][g], acc[mi][1][g]};
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                // mask bit of element (mi, g, ni), numbered in the order this loop visits them (the shifts below
+                // insert in that order): at bit 31 - (bit & 31) of word bit >> 5
+                const int bit = mi * 32 + 2 * g + ni;
+                if constexpr (MODE == 1) {
+                    const unsigned t = __builtin_bit_cast(unsigned, v[ni]);
+                    if (bit < 32) mlo = __builtin_amdgcn_alignbit(mlo, t, 31);
+                    else mhi = __builtin_amdgcn_alignbit(mhi, t, 31);
+                    asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v[ni]) : "v"(v[ni]));
+                }
+                if constexpr (MODE == 3) v[ni] = fmaf(dsig_lds[row0 + 4 * h], sw[ni], v[ni]);
+                if constexpr (MODE == 2 || MODE == 3) {
+                    const int keep = __builtin_amdgcn_sbfe((int)(bit < 32 ? blo : bhi), 31 - (bit & 31), 1);   // 0 or all ones
+                    v[ni] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[ni]) & keep);
+                }
+            }
+            if (gout) {
+                // 8 bytes per lane, 256 contiguous bytes per row and store (a 64-bit store is exempt from the wide-store
+                // data hazard that keeps the 16-byte stores of the fp32 kernels on immediate offsets)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, (f32x2){v[0], v[1]}), g_rsrc, g_voff,
+                                                      row0 * lay::H * 4, 2);
+            }
+            if constexpr (TO_PLANES) {
+                unsigned w[3];
+                split2(v[0], v[1], w);
+                store_terms(planes, (row0 + 4 * h) * LDPB + col * 2, w);
+            }
+        }
+    if constexpr (MODE == 1) {
+        if (mask_out) *mask_out = ((unsigned long long)mhi << 32) | mlo;
+    }
+}
+
+// ---- forward --------------------------------------------------------------------------------------------
+struct X3FwdArgs {
+    const float* pk;       // fp32 image (thin vectors, biases)
+    const __bf16* x3;      // the bf16x3 planes
+    int64_t M;
+    size_t Mp;
+    const float* points;
+    const float* dirs;
+    const float* rays_o;
+    const float* rays_d;
+    const float* t;
+    int S;
+    int t_per_ray;
+    float nearf, spanf;
+    float* colors;
+    float* density;
+    float* ws;
+};
+
+__device__ __forceinline__ float norm_coord_x3(float p, float nearf, float spanf) {
+#pragma clang fp contract(off)  // each operation rounded on its own, as the reference's tensor ops are
+    return sub_rn(div_rn(mul_rn(2.0f, sub_rn(p, nearf)), spanf), 1.0f);
+}
+
+// xin[s][0..2] = normalised position, xin[s][3..5] = direction (zeros beyond M); xin[6], xin[7] (padding of row 0): the
+// tile's largest |position| / |direction| component (range check of the table-form encodings)
+__device__ __forceinline__ void x3_load_inputs(const X3FwdArgs& a, size_t m0, float* xin, int tid) {
+#pragma clang fp contract(off)  // o + t*d must not become an FMA (bit-exact positions)
+    if (tid < TR) {
+        const size_t m = m0 + tid;
+        float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+        if (m < (size_t)a.M) {
+            if (a.points) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { x[c] = a.points[m * 3 + c]; d[c] = a.dirs[m * 3 + c]; }
+            } else {
+                const size_t ray = m / (size_t)a.S;
+                const float ts = a.t_per_ray ? a.t[m] : a.t[m - ray * (size_t)a.S];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    d[c] = a.rays_d[ray * 3 + c];
+                    x[c] = norm_coord_x3(add_rn(a.rays_o[ray * 3 + c], mul_rn(ts, d[c])), a.nearf, a.spanf);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xin[tid * 8 + c] = x[c]; xin[tid * 8 + 3 + c] = d[c]; }
+        float big = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fabsf(x[2]));
+        float bigd = fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fabsf(d[2]));
+#pragma unroll
+        for (int off = TR / 2; off >= 1; off >>= 1) {
+            big = fmaxf(big, __shfl_xor(big, off, TR));
+            bigd = fmaxf(bigd, __shfl_xor(bigd, off, TR));
+        }
+        if (tid == 0) { xin[6] = big; xin[7] = bigd; }
+    }
+}
+
+// The encoding of one sample row: values into the planes (three terms each) and, when `stage` is given, as fp32 into a
+// staging row (for the workspace copy).  Table form (EncCache) or, for tiles whose arguments leave its range, the
+// full-range sine/cosine -- value for value what the fp32 kernels compute.
+template <int L>
+__device__ __forceinline__ void x3_enc_put(unsigned char* planes, float* stage, int row, int col, float v) {
+    store_value(planes, row, col, v);
+    if (stage) stage[col] = v;
+}
+template <int L>
+__device__ __forceinline__ void x3_enc_store(unsigned char* planes, float* stage, int row, int q, const EncCache<L>& c) {
+    constexpr int R = EncCache<L>::ROUNDS;
+    const bool extra = q == 3;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (enc_round_active<L>(q, i)) {
+            const int base = extra ? 48 + i : 12 * i + q;
+            x3_enc_put<L>(planes, stage, row, base + 3, c.sn[i][0]);
+            x3_enc_put<L>(planes, stage, row, base + 6, c.cs[i][0]);
+            x3_enc_put<L>(planes, stage, row, base + 9, c.sn[i][1]);
+            x3_enc_put<L>(planes, stage, row, base + 12, c.cs[i][1]);
+        }
+    }
+    if (!extra) x3_enc_put<L>(planes, stage, row, q, c.x);
+    else {
+#pragma unroll
+        for (int col = 3 + 6 * L; col < ((3 + 6 * L + 15) & ~15); ++col) x3_enc_put<L>(planes, stage, row, col, 0.0f);
+    }
+}
+template <int L>
+__device__ __forceinline__ void x3_enc_slow(unsigned char* planes, float* stage, int row, int q, const float* xs) {
+    if (q < 3) {
+        const float x = xs[q];
+        x3_enc_put<L>(planes, stage, row, q, x);
+        float scale = 1.0f;
+#pragma unroll 1
+        for (int j = 0; j < L; ++j) {
+            float s, c;
+            nerf_sincosf(mul_rn(scale, x), &s, &c);
+            x3_enc_put<L>(planes, stage, row, 3 + 6 * j + q, s);
+            x3_enc_put<L>(planes, stage, row, 3 + 6 * j + 3 + q, c);
+            scale *= 2.0f;
+        }
+    } else {
+#pragma unroll
+        for (int col = 3 + 6 * L; col < ((3 + 6 * L + 15) & ~15); ++col) x3_enc_put<L>(planes, stage, row, col, 0.0f);
+    }
+}
+
+// copy a [64][WIDTH] fp32 staging tile (row pitch LDPB bytes) to global rows of WIDTH floats
+template <int WIDTH>
+__device__ __forceinline__ void x3_copy_stage(const unsigned char* stage0, float* __restrict__ g, int tid) {
+    constexpr int C4 = WIDTH / 4;
+#pragma unroll
+    for (int i = tid; i < TR * C4; i += 256) {
+        const int row = i / C4, c4 = i % C4;
+        *reinterpret_cast<f32x4*>(g + (size_t)row * WIDTH + 4 * c4) = *reinterpret_cast<const f32x4*>(stage0 + row * LDPB + 16 * c4);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void nerf_fwd_x3_kernel(X3FwdArgs a) {
+    using namespace lay;
+    using namespace lay::nerf;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
+    float* tab = reinterpret_cast<float*>(smem_x3);
+    unsigned char* planes = smem_x3 + SINCOS_TAB_FLOATS * 4;
+    float* xin = reinterpret_cast<float*>(planes + PLANES_BYTES);
+    float* sraw_s = xin + X3_XIN_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t m0 = (size_t)blockIdx.x * TR;
+    const float* __restrict__ pk = a.pk;
+    const __bf16* __restrict__ xi = a.x3;
+    float* ws = a.ws;
+    const size_t Mp = a.Mp;
+    auto wsp = [&](size_t off, int width) -> float* { return ws + off * Mp + m0 * width; };
+    auto mskp = [&](int l) -> mask_t* { return reinterpret_cast<mask_t*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid; };
+    const int smp = tid / TPS, q = tid % TPS;
+    // fp32 staging rows of the encodings: bytes 128.. of plane 0's rows (columns 64.. of a plane are unused while the
+    // encoding is a layer's input)
+    unsigned char* stage0 = planes + 128;
+
+    load_sincos_table(tab, tid);
+    x3_load_inputs(a, m0, xin, tid);
+    __syncthreads();
+    const auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    const bool pe_fast = uniform(xin[6]) * 512.0f <= 9.9e4f;
+    EncCache<10> pec;
+    if (pe_fast) {
+        enc_compute<10>(xin + smp * 8, q, pec);
+        x3_enc_store<10>(planes, reinterpret_cast<float*>(stage0 + smp * LDPB), smp, q, pec);
+    } else {
+        x3_enc_slow<10>(planes, reinterpret_cast<float*>(stage0 + smp * LDPB), smp, q, xin + smp * 8);
+    }
+    __syncthreads();
+    x3_copy_stage<PE_P>(stage0, wsp(WS_PE, PE_P), tid);
+
+    const int ncol0 = wave * 64;
+    f32x16 acc[MT][2];
+    // L0
+    mma_layer_x3<2, PE_P / 16, ACC_BIAS>(planes, xi + x3::F_L0, H, ncol0, lane, acc, pk + BIAS);
+    __syncthreads();
+    x3_epilogue<1, true>(planes, acc, ncol0, lane, wsp(WS_H, H), mskp(0), 0, nullptr, nullptr);
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l <= 4; ++l) {
+        mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L1 + (size_t)(l - 1) * x3::elems(H, H), H, ncol0, lane, acc,
+                                          pk + BIAS + l * H);
+        __syncthreads();
+        x3_epilogue<1, true>(planes, acc, ncol0, lane, wsp(WS_H + (size_t)l * H, H), mskp(l), 0, nullptr, nullptr);
+        __syncthreads();
+    }
+    // L5: [h4 | pe]
+    mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L5A, H, ncol0, lane, acc, pk + BIAS + 5 * H);
+    __syncthreads();
+    if (pe_fast) x3_enc_store<10>(planes, nullptr, smp, q, pec);
+    else x3_enc_slow<10>(planes, nullptr, smp, q, xin + smp * 8);
+    __syncthreads();
+    mma_layer_x3<2, PE_P / 16, ACC_KEEP>(planes, xi + x3::F_L5B, H, ncol0, lane, acc);
+    __syncthreads();
+    x3_epilogue<1, true>(planes, acc, ncol0, lane, wsp(WS_H + 5 * (size_t)H, H), mskp(5), 0, nullptr, nullptr);
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 6; l <= 8; ++l) {
+        mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L6 + (size_t)(l - 6) * x3::elems(H, H), H, ncol0, lane, acc,
+                                          pk + BIAS + l * H);
+        __syncthreads();
+        x3_epilogue<1, true>(planes, acc, ncol0, lane, wsp(WS_H + (size_t)l * H, H), mskp(l), 0, nullptr, nullptr);
+        __syncthreads();
+    }
+    // L9: 256 feature columns on MFMA; the density row is a dot product of h8 with the 257th weight row, taken from
+    // the fp32 copy of h8 that the epilogue above has just written to the workspace (the planes hold it as bf16 terms)
+    mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L9, H, ncol0, lane, acc, pk + BIAS + 9 * H);
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave's h8 stores are complete (they bypass no cache this workgroup reads through)
+        const float* h8 = wsp(WS_H + 8 * (size_t)H, H) + (size_t)smp * H;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = 4 * (TPS * i + q);
+            const f32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h8 + k));
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + SIGW + k);
+            s += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += pk[BIAS_SIG];
+        if (q == 0) {
+            sraw_s[smp] = s;
+            ws[WS_SRAW * Mp + m0 + smp] = s;
+        }
+    }
+    x3_epilogue<0, true>(planes, acc, ncol0, lane, wsp(WS_F, H), nullptr, 0, nullptr, nullptr);
+    __syncthreads();
+    // L10: [f | de] -> 128, ReLU
+    {
+        const int nc = wave * 32;
+        f32x16 acc1[MT][1];
+        mma_layer_x3<1, H / 16, ACC_BIAS>(planes, xi + x3::F_L10A, HH, nc, lane, acc1, pk + BIAS10);
+        __syncthreads();
+        unsigned char* stage_de = planes + 128;   // columns 64.. are free: the direction encoding is 32 wide
+        float* st = reinterpret_cast<float*>(stage_de + smp * LDPB);
+        if (uniform(xin[7]) * 8.0f <= 9.9e4f) {
+            EncCache<4> dec;
+            enc_compute<4>(xin + smp * 8 + 3, q, dec);
+            x3_enc_store<4>(planes, st, smp, q, dec);
+        } else {
+            x3_enc_slow<4>(planes, st, smp, q, xin + smp * 8 + 3);
+        }
+        __syncthreads();
+        x3_copy_stage<DE_P>(stage_de, wsp(WS_DE, DE_P), tid);
+        mma_layer_x3<1, DE_P / 16, ACC_KEEP>(planes, xi + x3::F_L10B, HH, nc, lane, acc1);
+        __syncthreads();
+        // epilogue: g = max(0, -n) as fp32 into the plane area (viewed as [64][LDG] floats) for the head, and to the workspace
+        float* gt = reinterpret_cast<float*>(planes);
+        float* gg = wsp(WS_G, HH);
+        const int col = nc + (lane & 31);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = acc_row(mi, g, lane);
+                float v = acc1[mi][0][g];
+                asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v) : "v"(v));
+                gt[row * LDG + col] = v;
+                gg[(size_t)row * HH + col] = v;
+            }
+        __syncthreads();
+        // L11 + sigmoid, density = relu(raw)
+        float z[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 4 * (TPS * i + q);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gt + smp * LDG + k);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + W11 + c * HH + k);
+                z[c] += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            z[c] += __shfl_xor(z[c], 1);
+            z[c] += __shfl_xor(z[c], 2);
+        }
+        const size_t m = m0 + smp;
+        if (q == 0 && m < (size_t)a.M) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.colors[m * 3 + c] = sigmoidf_(z[c] + pk[BIAS11 + c]);
+            a.density[m] = fmaxf(sraw_s[smp], 0.0f);
+        }
+    }
+}
+
+// ---- data gradient ----------------------------------------------------------------------------------------
+struct X3BwdArgs {
+    const float* pk;
+    const __bf16* x3;
+    int64_t M;
+    size_t Mp;
+    const float* dcolors;
+    const float* ddensity;
+    const float* colors;
+    const float* ws;
+    float* bw;
+};
+
+__global__ __launch_bounds__(256, 1) void nerf_dgrad_x3_kernel(X3BwdArgs a) {
+    using namespace lay;
+    using namespace lay::nerf;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
+    unsigned char* planes = smem_x3;
+    float* dsig_s = reinterpret_cast<float*>(planes + PLANES_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t m0 = (size_t)blockIdx.x * TR;
+    const size_t Mp = a.Mp;
+    const float* __restrict__ pk = a.pk;
+    const __bf16* __restrict__ xi = a.x3;
+    const float* ws = a.ws;
+    float* bw = a.bw;
+    const int ncol0 = wave * 64;
+    auto dzp = [&](int l) { return bw + (BW_DZ + (size_t)l * H) * Mp + m0 * H; };
+    auto mskp = [&](int l) { return reinterpret_cast<const mask_t*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid; };
+
+    // gradient of the 128 -> 3 sigmoid head (head_bwd of mlp_bwd.hip), its result dz10 [64][128] into the planes
+    {
+        const int smp = tid / TPS, q = tid % TPS;
+        const size_t m = m0 + smp;
+        float dz[3] = {0.f, 0.f, 0.f};
+        float ds = 0.f;
+        if (m < (size_t)a.M) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float col = a.colors[m * 3 + c];
+                dz[c] = a.dcolors[m * 3 + c] * col * (1.0f - col);
+            }
+            ds = ws[WS_SRAW * Mp + m] > 0.0f ? a.ddensity[m] : 0.0f;
+        }
+        if (q == 0) {
+            f32x4 v = {dz[0], dz[1], dz[2], 0.0f};
+            *reinterpret_cast<f32x4*>(bw + BW_DZ11 * Mp + m * 4) = v;
+            bw[BW_DSIG * Mp + m] = ds;
+            dsig_s[smp] = ds;
+        }
+        const float* wout = pk + W11;
+        const float* gsrc = ws + WS_G * Mp;
+        float* bw_dzr = bw + BW_DZ10 * Mp;
+#pragma unroll
+        for (int i = 0; i < 32 / TPS; ++i) {
+            const int k = 4 * (TPS * i + q);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wout + k);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wout + HH + k);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wout + 2 * HH + k);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gsrc + m * HH + k);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = dz[0] * w0[e] + dz[1] * w1[e] + dz[2] * w2[e];
+                v[e] = gv[e] > 0.0f ? d : 0.0f;
+            }
+            *reinterpret_cast<f32x4*>(bw_dzr + m * HH + k) = v;
+            unsigned wa[3], wb[3];
+            split2(v[0], v[1], wa);
+            split2(v[2], v[3], wb);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<u32x2_t*>(planes + p * PLANE_BYTES + smp * LDPB + k * 2) = u32x2_t{wa[p], wb[p]};
+        }
+    }
+    __syncthreads();
+    f32x16 acc[MT][2];
+    // rgb_head.0 (feature part): reduce over its 128 outputs -> dz9, the gradient of the 256 features
+    mma_layer_x3<2, HH / 16, ACC_ZERO>(planes, xi + x3::D10, H, ncol0, lane, acc);
+    __syncthreads();
+    x3_epilogue<4, true>(planes, acc, ncol0, lane, bw + BW_DZ9 * Mp + m0 * H, nullptr, 0, nullptr, nullptr);
+    __syncthreads();
+    // block2.8: feature rows on MFMA + the density row as a rank-1 term, ReLU mask of h8 -> dz8
+    {
+        const mask_t bits = *mskp(8);
+        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(9), H, ncol0, lane, acc);
+        __syncthreads();
+        x3_epilogue<3, true>(planes, acc, ncol0, lane, dzp(8), nullptr, bits, dsig_s, pk + SIGW);
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int l = 8; l >= 2; --l) {
+        const mask_t bits = *mskp(l - 1);
+        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(l), H, ncol0, lane, acc);
+        __syncthreads();
+        x3_epilogue<2, true>(planes, acc, ncol0, lane, dzp(l - 1), nullptr, bits, nullptr, nullptr);
+        __syncthreads();
+    }
+    {
+        const mask_t bits = *mskp(0);
+        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(1), H, ncol0, lane, acc);
+        x3_epilogue<2, false>(planes, acc, ncol0, lane, dzp(0), nullptr, bits, nullptr, nullptr);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t nerf_mlp_packed_x3_floats(int model) {
+    return model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS + x3::TOTAL_FLOATS : 0;
+}
+
+extern "C" int nerf_mlp_pack_x3(int model, const float* const* params, float* packed, void* stream) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_pack_x3: the bf16x3 training mode covers the NeRF model only (model %d)", model);
+    NERF_REQUIRE_PTR(params);
+    NERF_REQUIRE_PTR(packed);
+    int rc = nerf_mlp_pack(model, params, packed, stream);   // the fp32 image comes first (thin vectors, biases, inference)
+    if (rc) return rc;
+    using namespace lay;
+    X3PackArgs a;
+    for (int i = 0; i < NERF_NUM_PARAM_TENSORS; ++i) a.src[i] = params[i];
+    a.dst = reinterpret_cast<__bf16*>(packed + lay::nerf::PACKED_FLOATS);
+    a.njobs = 0;
+    x3_fwd_job(a, 0, PE, 0, H, PE, x3::F_L0, true, true);
+    for (int l = 1; l <= 4; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3::F_L1 + (size_t)(l - 1) * x3::elems(H, H), true, true);
+    x3_fwd_job(a, 10, H + PE, 0, H, H, x3::F_L5A, true, true);
+    x3_fwd_job(a, 10, H + PE, H, H, PE, x3::F_L5B, true, true);
+    for (int l = 6; l <= 8; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3::F_L6 + (size_t)(l - 6) * x3::elems(H, H), true, true);
+    x3_fwd_job(a, 18, H, 0, H, H, x3::F_L9, false, true);
+    x3_fwd_job(a, 20, H + DE, 0, HH, H, x3::F_L10A, true, false);
+    x3_fwd_job(a, 20, H + DE, H, HH, DE, x3::F_L10B, true, false);
+    x3_bwd_job(a, 20, H + DE, H, HH, x3::D10);
+    x3_bwd_job(a, 18, H, H, H, x3::d_img(9));
+    for (int l = 8; l >= 6; --l) x3_bwd_job(a, 2 * l, H, H, H, x3::d_img(l));
+    x3_bwd_job(a, 10, H + PE, H, H, x3::d_img(5));
+    for (int l = 4; l >= 1; --l) x3_bwd_job(a, 2 * l, H, H, H, x3::d_img(l));
+    pack_x3_kernel<<<dim3(a.njobs, 64), 256, 0, (hipStream_t)stream>>>(a);
+    return nerf_check_launch("nerf_mlp_pack_x3");
+}
+
+extern "C" int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const float* points, const float* dirs,
+                               const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near,
+                               double far, float* colors, float* density, float* workspace, void* stream) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_fwd_x3: the bf16x3 training mode covers the NeRF model only (model %d)", model);
+    NERF_REQUIRE(M >= 0, "nerf_mlp_fwd_x3: M=%lld < 0", (long long)M);
+    if (M == 0) return NERF_OK;
+    NERF_REQUIRE_PTR(packed);
+    NERF_REQUIRE_PTR(colors);
+    NERF_REQUIRE_PTR(density);
+    NERF_REQUIRE_PTR(workspace);
+    if (points) {
+        NERF_REQUIRE_PTR(dirs);
+    } else {
+        NERF_REQUIRE_PTR(rays_o);
+        NERF_REQUIRE_PTR(rays_d);
+        NERF_REQUIRE_PTR(t);
+        NERF_REQUIRE(S >= 1 && M % S == 0, "nerf_mlp_fwd_x3: ray mode needs M (%lld) to be a multiple of S (%d)", (long long)M, S);
+    }
+    const size_t mp = lay::padded_samples(M);
+    const size_t tiles = mp / TR;
+    NERF_REQUIRE(tiles < (1ull << 31), "nerf_mlp_fwd_x3: too many samples");
+    X3FwdArgs a{packed, reinterpret_cast<const __bf16*>(packed + lay::nerf::PACKED_FLOATS), M, mp, points, dirs, rays_o, rays_d,
+                t, S, t_per_ray, (float)near, (float)(far - near), colors, density, workspace};
+    int rc;
+    if ((rc = nerf_set_lds(nerf_fwd_x3_kernel, X3_FWD_LDS_BYTES))) return rc;
+    nerf_fwd_x3_kernel<<<(unsigned)tiles, 256, X3_FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    return nerf_check_launch("nerf_mlp_fwd_x3");
+}
+
+extern "C" int nerf_mlp_bwd_data_x3(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
+                                    const float* colors, const float* fwd_workspace, float* bwd_workspace, void* stream) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_bwd_data_x3: the bf16x3 training mode covers the NeRF model only (model %d)", model);
+    NERF_REQUIRE(M >= 1, "nerf_mlp_bwd_data_x3: M=%lld < 1", (long long)M);
+    NERF_REQUIRE_PTR(packed);
+    NERF_REQUIRE_PTR(dcolors);
+    NERF_REQUIRE_PTR(ddensity);
+    NERF_REQUIRE_PTR(colors);
+    NERF_REQUIRE_PTR(fwd_workspace);
+    NERF_REQUIRE_PTR(bwd_workspace);
+    const size_t Mp = lay::padded_samples(M);
+    NERF_REQUIRE(Mp / TR < (1ull << 31), "nerf_mlp_bwd_data_x3: too many samples");
+    X3BwdArgs a{packed, reinterpret_cast<const __bf16*>(packed + lay::nerf::PACKED_FLOATS), M, Mp, dcolors, ddensity, colors,
+                fwd_workspace, bwd_workspace};
+    int rc;
+    if ((rc = nerf_set_lds(nerf_dgrad_x3_kernel, X3_BWD_LDS_BYTES))) return rc;
+    nerf_dgrad_x3_kernel<<<(unsigned)(Mp / TR), 256, X3_BWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    return nerf_check_launch("nerf_mlp_bwd_data_x3");
+}

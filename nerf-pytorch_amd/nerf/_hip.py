@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 MODEL_NERF = 0
 MODEL_SIREN = 1
 NUM_PARAM_TENSORS = 24
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -53,6 +53,10 @@ _SIGS = {
     "nerf_mlp_packed_bf16x3_bytes": (c_size_t, [c_int]),
     "nerf_mlp_pack_bf16x3": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
     "nerf_mlp_fwd_bf16x3": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P, _P, _P]),
+    "nerf_mlp_packed_x3_floats": (c_size_t, [c_int]),
+    "nerf_mlp_pack_x3": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
+    "nerf_mlp_fwd_x3": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P, _P, _P, _P]),
+    "nerf_mlp_bwd_data_x3": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "nerf_linear_bwd_workspace_floats": (c_size_t, [c_int64, c_int, c_int]),
     "nerf_linear_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_double, c_double, _P, c_int64, _P, _P]),
     "nerf_linear_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_double, c_double, _P, c_int64, _P, c_int64, c_int,
@@ -265,6 +269,27 @@ def mlp_pack(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Ten
     return out
 
 
+def mlp_pack_x3(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight image of the opt-in bf16x3 TRAINING mode: the fp32 image of mlp_pack followed by the three-term bf16
+    planes of every dense layer, forward and transposed.  mlp_fwd / mlp_bwd recognise it by its size; a pass without a
+    workspace (inference) reads the fp32 part alone."""
+    if len(params) != NUM_PARAM_TENSORS:
+        raise ValueError(f"expected {NUM_PARAM_TENSORS} parameter tensors, got {len(params)}")
+    n = lib.nerf_mlp_packed_x3_floats(model)
+    if n == 0:
+        raise NotImplementedError("the bf16x3 training mode covers the NeRF model only")
+    if out is None or out.numel() != n:
+        out = torch.empty(n, dtype=torch.float32, device=params[0].device)
+    ptrs = (c_void_p * NUM_PARAM_TENSORS)(*[_dev(p, f"params[{i}]") for i, p in enumerate(params)])
+    _check(lib.nerf_mlp_pack_x3(model, ptrs, _dev(out, "packed"), _stream()), "nerf_mlp_pack_x3")
+    return out
+
+
+def is_x3_image(model: int, packed: torch.Tensor) -> bool:
+    n = lib.nerf_mlp_packed_x3_floats(model)
+    return n != 0 and packed.dtype == torch.float32 and packed.numel() == n
+
+
 def mlp_fwd(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None, rays_o=None, rays_d=None, t=None,
             S: int = 0, near: float = 0.0, far: float = 1.0, train: bool = False, want_colors: bool = True):
     """want_colors=False (inference only): the pass stops after the density row / branch; colors come back as None."""
@@ -276,12 +301,14 @@ def mlp_fwd(model: int, packed: torch.Tensor, M: int, *, points=None, dirs=None,
     ws = None
     if train:
         ws = torch.empty(lib.nerf_mlp_fwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
-    ev = timers.start("mlp_fwd_train" if train else ("mlp_fwd_infer" if want_colors else "mlp_fwd_infer_density"), M)
-    _check(lib.nerf_mlp_fwd(model, _dev(packed, "packed"), M, _opt(points, "points"), _opt(dirs, "dirs"),
-                            _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S,
-                            int(t is not None and t.dim() == 2), float(near), float(far),
-                            _opt(colors, "colors"), _dev(density, "density"), _opt(ws, "workspace"), _stream()),
-           "nerf_mlp_fwd")
+    x3 = train and is_x3_image(model, packed)     # the opt-in bf16x3 training kernels; inference reads the fp32 part
+    ev = timers.start(("mlp_fwd_train_x3" if x3 else "mlp_fwd_train") if train else ("mlp_fwd_infer" if want_colors else "mlp_fwd_infer_density"), M)
+    _check((lib.nerf_mlp_fwd_x3 if x3 else lib.nerf_mlp_fwd)(
+        model, _dev(packed, "packed"), M, _opt(points, "points"), _opt(dirs, "dirs"),
+        _opt(rays_o, "rays_o"), _opt(rays_d, "rays_d"), _opt(t, "t"), S,
+        int(t is not None and t.dim() == 2), float(near), float(far),
+        _opt(colors, "colors"), _dev(density, "density"), _opt(ws, "workspace"), _stream()),
+        "nerf_mlp_fwd_x3" if x3 else "nerf_mlp_fwd")
     timers.stop(ev)
     return colors, density, ws
 
@@ -342,10 +369,12 @@ def mlp_bwd(model: int, packed: torch.Tensor, M: int, dcolors, ddensity, colors,
     elif grads.dim() != 1 or grads.numel() != param_floats(model):
         raise ValueError(f"gradient buffer must be a flat tensor of {param_floats(model)} floats, got {tuple(grads.shape)}")
     bw = torch.empty(lib.nerf_mlp_bwd_workspace_floats(model, M), dtype=torch.float32, device=dev)
-    ev = timers.start("mlp_bwd_data", M)
-    _check(lib.nerf_mlp_bwd_data(model, _dev(packed, "packed"), M, _dev(dcolors, "dcolors"), _dev(ddensity, "ddensity"),
-                                 _dev(colors, "colors"), _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
-                                 _stream()), "nerf_mlp_bwd_data")
+    x3 = is_x3_image(model, packed)   # the workspace then comes from the bf16x3 forward (its mask words are laid out differently)
+    ev = timers.start("mlp_bwd_data_x3" if x3 else "mlp_bwd_data", M)
+    _check((lib.nerf_mlp_bwd_data_x3 if x3 else lib.nerf_mlp_bwd_data)(
+        model, _dev(packed, "packed"), M, _dev(dcolors, "dcolors"), _dev(ddensity, "ddensity"),
+        _dev(colors, "colors"), _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
+        _stream()), "nerf_mlp_bwd_data_x3" if x3 else "nerf_mlp_bwd_data")
     timers.stop(ev)
     ev = timers.start("mlp_bwd_weights", M)
     _check(lib.nerf_mlp_bwd_weights(model, M, _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_hip.lib, s), f"libnerf_hip.so does not export {s}"
         assert s in _hip.EXPORTS, f"{s} declared in nerf_hip.h but not bound in nerf/_hip.py"
-    assert _hip.lib.nerf_abi_version() == 9
+    assert _hip.lib.nerf_abi_version() == 10
 
 
 def test_sizes_match_reference_parameter_counts():
