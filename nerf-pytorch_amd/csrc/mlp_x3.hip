@@ -20,7 +20,11 @@
 //     so that a lane owns two ADJACENT columns of every row: one packed bf16 pair per LDS write, one 8-byte store per
 //     row for the fp32 copy of the tile that goes to the workspace straight from the registers (the fp32 kernels
 //     copy it from their fp32 LDS tile inside the next MFMA loop; there is no fp32 tile here);
-//   * 101 KiB of planes: one workgroup per CU, one wave per SIMD.
+//   * 101 KiB of planes allow one workgroup per CU, so the workgroup is EIGHT waves: waves 0..3 own rows 0..31 of
+//     the tile, waves 4..7 rows 32..63 (a 32 x 64 accumulator block each) -- two waves per SIMD, so that one wave's
+//     MFMAs cover the other's fragment waits, and the dependent chains of the splitting epilogue interleave.  Waves w
+//     and w + 4 fetch the same weight fragments (the second fetch hits the CU's vector cache).  The per-sample phases
+//     (encodings, heads: four threads per sample) run on the first 256 threads.
 #include "mlp_device.h"
 
 using namespace dev;
@@ -31,7 +35,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
-static_assert(TR == 64 && MT == 2 && TPS == 4, "the bf16x3 training kernels are written for 64-row tiles");
+static_assert(TR == 64 && TPS == 4, "the bf16x3 training kernels are written for 64-row tiles");
+constexpr int X3_THREADS = 512;
+typedef unsigned xmask_t;   // (h > 0) bits of one lane's 32 accumulator registers of a 256-wide layer
 
 // ---- LDS ----------------------------------------------------------------------------------------------
 constexpr int LDPB = 528;                        // bytes per plane row: 256 bf16 + 16 bytes (bank spread of the A reads)
@@ -124,64 +130,90 @@ void x3_bwd_job(X3PackArgs& a, int tensor, int ld, int Nin, int Kout, size_t dst
 // planes (global, position ncol0 + 32 ni + r).  Fully unrolled (KS is 2, 4, 8 or 16): fragment sets rotate by
 // compile-time index; the weight fragments of k-step ks + 2 and the activation fragments of ks + 1 are requested before
 // the 24 (NT = 2) MFMAs of k-step ks -- with one wave per SIMD nothing else hides the L2 latency.
+// What a K loop needs from global memory before its first MFMA: the weight fragments of its first PFB - 1 k-steps and the
+// bias of the wave's columns.  Requested by the caller BEFORE the previous layer's epilogue (x3_prefetch): the L2 round
+// trip then runs under the epilogue, and -- this device has one counter for loads and stores -- the wait for these
+// fragments does not also wait for the epilogue's workspace stores, which are younger.
+#ifndef X3_PFB
+#define X3_PFB 3
+#endif
+constexpr int PFB = X3_PFB;                      // weight fragments are requested PFB - 1 k-steps ahead
+template <int NT>
+struct X3Pre {
+    bf16x8 b[PFB - 1][NT][3];
+    float bias[NT];
+};
+template <int NT>
+__device__ __forceinline__ void x3_load_b(__amdgpu_buffer_rsrc_t rsrc, int b_voff, int plane_elems, int N, int ks,
+                                          bf16x8 (&b)[NT][3]) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            b[ni][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      rsrc, b_voff + ni * 32 * 32, (p * plane_elems + ks * N * 16) * 2, 0));
+}
 template <int NT, int KS, int INIT>
-__device__ __forceinline__ void mma_layer_x3(const unsigned char* planes, const __bf16* __restrict__ img, int N, int ncol0,
-                                             int lane, f32x16 (&acc)[MT][NT], const float* __restrict__ bias = nullptr) {
+__device__ __forceinline__ void x3_prefetch(const __bf16* __restrict__ img, int N, int ncol0, int lane,
+                                            const float* __restrict__ bias, X3Pre<NT>& pre) {
     const int r = lane & 31, h = lane >> 5;
-    float bias_v[NT];
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
         // the accumulator's column: interleaved for the two-tile layers (see the header of this file)
         const int col = NT == 2 ? ncol0 + 2 * r + ni : ncol0 + r;
-        bias_v[ni] = (INIT == ACC_BIAS) ? bias[col] : 0.0f;
+        pre.bias[ni] = (INIT == ACC_BIAS) ? bias[col] : 0.0f;
     }
     const int plane_elems = KS * 16 * N;
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(img, (unsigned)(3 * plane_elems * 2));
     const int b_voff = ((ncol0 + r) * 16 + 8 * h) * 2;
-    const unsigned char* a_ptr = planes + r * LDPB + 16 * h;
-    bf16x8 A[2][MT][3], B[3][NT][3];
-    auto load_b = [&](int ks, bf16x8 (&b)[NT][3]) {
+#pragma unroll
+    for (int i = 0; i < PFB - 1; ++i)
+        if (i < KS) x3_load_b<NT>(rsrc, b_voff, plane_elems, N, i, pre.b[i]);
+}
+
+template <int NT, int KS, int INIT>
+__device__ __forceinline__ void mma_layer_x3(const unsigned char* planes, const __bf16* __restrict__ img, int N, int ncol0,
+                                             int wrow0, int lane, f32x16 (&acc)[NT], const X3Pre<NT>& pre) {
+    const int r = lane & 31, h = lane >> 5;
+    const int plane_elems = KS * 16 * N;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(img, (unsigned)(3 * plane_elems * 2));
+    const int b_voff = ((ncol0 + r) * 16 + 8 * h) * 2;
+    const unsigned char* a_ptr = planes + (wrow0 + r) * LDPB + 16 * h;
+    bf16x8 A[2][3], B[PFB][NT][3];
+    auto load_a = [&](int ks, bf16x8 (&a)[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(a_ptr + p * PLANE_BYTES + ks * 32);
+    };
+#pragma unroll
+    for (int i = 0; i < PFB - 1; ++i)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                b[ni][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          rsrc, b_voff + ni * 32 * 32, (p * plane_elems + ks * N * 16) * 2, 0));
-    };
-    auto load_a = [&](int ks, bf16x8 (&a)[MT][3]) {
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                a[mi][p] = *reinterpret_cast<const bf16x8*>(a_ptr + p * PLANE_BYTES + mi * 32 * LDPB + ks * 32);
-    };
-    load_b(0, B[0]);
-    if constexpr (KS > 1) load_b(1, B[1]);
+            for (int p = 0; p < 3; ++p) B[i][ni][p] = pre.b[i][ni][p];
     load_a(0, A[0]);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 2 < KS) load_b(ks + 2, B[(ks + 2) % 3]);
+        if (ks + PFB - 1 < KS) x3_load_b<NT>(rsrc, b_voff, plane_elems, N, ks + PFB - 1, B[(ks + PFB - 1) % PFB]);
         if (ks + 1 < KS) load_a(ks + 1, A[(ks + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 (&a)[MT][3] = A[ks & 1];
-        const bf16x8 (&b)[NT][3] = B[ks % 3];
+        const bf16x8 (&a)[3] = A[ks & 1];
+        const bf16x8 (&b)[NT][3] = B[ks % PFB];
+        f32x16 c[NT];
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+        for (int ni = 0; ni < NT; ++ni) {
+            if (ks == 0 && INIT == ACC_ZERO) c[ni] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            else if (ks == 0 && INIT == ACC_BIAS) c[ni] = splat16(pre.bias[ni]);
+            else c[ni] = acc[ni];
+        }
+        // the six term products, alternating between the wave's accumulators (every product is exact, the sum rounds
+        // like an fp32 accumulation whatever the order)
+        constexpr int TA[6] = {0, 0, 0, 1, 1, 2}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                f32x16 c;
-                if (ks == 0 && INIT == ACC_ZERO) c = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                else if (ks == 0 && INIT == ACC_BIAS) c = splat16(bias_v[ni]);
-                else c = acc[mi][ni];
-                // smallest terms first would not change what is exact: every product is exact, the sum rounds like fp32
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
-                acc[mi][ni] = c;
-            }
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) c[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]], b[ni][TB[t]], c[ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[ni] = c[ni];
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -222,54 +254,61 @@ __device__ __forceinline__ void store_value(unsigned char* planes, int row, int 
 //   MODE 4: backward, nothing
 // gout: this tile's [64][256] fp32 rows in the workspace (NULL: not stored).  TO_PLANES false: the last layer of a chain.
 template <int MODE, bool TO_PLANES>
-__device__ __forceinline__ void x3_epilogue(unsigned char* planes, f32x16 (&acc)[MT][2], int ncol0, int lane,
-                                            float* __restrict__ gout, mask_t* mask_out, mask_t mask_in,
+__device__ __forceinline__ void x3_epilogue(unsigned char* planes, f32x16 (&acc)[2], int ncol0, int wrow0, int lane,
+                                            float* __restrict__ gout, xmask_t* mask_out, xmask_t mask_in,
                                             const float* dsig_lds, const float* __restrict__ sigw) {
     const int r = lane & 31, h = lane >> 5;
     const int col = ncol0 + 2 * r;
-    unsigned mlo = 0u, mhi = 0u;
-    const unsigned blo = (unsigned)mask_in, bhi = (unsigned)((unsigned long long)mask_in >> 32);
+    unsigned mbits = 0u;
     const __amdgpu_buffer_rsrc_t g_rsrc = make_rsrc(gout, (unsigned)(TR * lay::H * 4));
-    const int g_voff = (4 * h * lay::H + col) * 4;
+    const int g_voff = ((wrow0 + 4 * h) * lay::H + col) * 4;
+    unsigned char* pl = planes + (wrow0 + 4 * h) * LDPB + col * 2;
     f32x2 sw = {0.f, 0.f};
     if constexpr (MODE == 3) sw = *reinterpret_cast<const f32x2*>(sigw + col);
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+    for (int g = 0; g < 16; ++g) {
+        const int row0 = (g & 3) + 8 * (g >> 2);      // + wrow0 + 4 h
+        float v[2] = {acc[0][g], acc[1][g]};
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int row0 = 32 * mi + (g & 3) + 8 * (g >> 2);      // + 4 h
-            float v[2] = {acc[mi][0][g], acc[mi][1][g]};
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                // mask bit of element (mi, g, ni), numbered in the order this loop visits them (the shifts below
-                // insert in that order): at bit 31 - (bit & 31) of word bit >> 5
-                const int bit = mi * 32 + 2 * g + ni;
-                if constexpr (MODE == 1) {
-                    const unsigned t = __builtin_bit_cast(unsigned, v[ni]);
-                    if (bit < 32) mlo = __builtin_amdgcn_alignbit(mlo, t, 31);
-                    else mhi = __builtin_amdgcn_alignbit(mhi, t, 31);
-                    asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v[ni]) : "v"(v[ni]));
-                }
-                if constexpr (MODE == 3) v[ni] = fmaf(dsig_lds[row0 + 4 * h], sw[ni], v[ni]);
-                if constexpr (MODE == 2 || MODE == 3) {
-                    const int keep = __builtin_amdgcn_sbfe((int)(bit < 32 ? blo : bhi), 31 - (bit & 31), 1);   // 0 or all ones
-                    v[ni] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[ni]) & keep);
-                }
+        for (int ni = 0; ni < 2; ++ni) {
+            // mask bit of element (g, ni), numbered in the order this loop visits them (the shifts below insert in that
+            // order): at bit 31 - bit of the lane's word
+            const int bit = 2 * g + ni;
+            if constexpr (MODE == 1) {
+                mbits = __builtin_amdgcn_alignbit(mbits, __builtin_bit_cast(unsigned, v[ni]), 31);
+                asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v[ni]) : "v"(v[ni]));
             }
-            if (gout) {
-                // 8 bytes per lane, 256 contiguous bytes per row and store (a 64-bit store is exempt from the wide-store
-                // data hazard that keeps the 16-byte stores of the fp32 kernels on immediate offsets)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, (f32x2){v[0], v[1]}), g_rsrc, g_voff,
-                                                      row0 * lay::H * 4, 2);
-            }
-            if constexpr (TO_PLANES) {
-                unsigned w[3];
-                split2(v[0], v[1], w);
-                store_terms(planes, (row0 + 4 * h) * LDPB + col * 2, w);
+            if constexpr (MODE == 3) v[ni] = fmaf(dsig_lds[wrow0 + row0 + 4 * h], sw[ni], v[ni]);
+            if constexpr (MODE == 2 || MODE == 3) {
+                const int keep = __builtin_amdgcn_sbfe((int)mask_in, 31 - bit, 1);   // 0 or all ones
+                v[ni] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[ni]) & keep);
             }
         }
+#ifdef X3_EXP_NOSTORE
+        if (false) {
+#else
+        if (gout) {
+#endif
+            // 8 bytes per lane, 256 contiguous bytes per row and store (a 64-bit store is exempt from the wide-store
+            // data hazard that keeps the 16-byte stores of the fp32 kernels on immediate offsets)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, (f32x2){v[0], v[1]}), g_rsrc, g_voff,
+                                                  row0 * lay::H * 4, 2);
+        }
+#ifdef X3_EXP_NOSPLIT
+        if constexpr (TO_PLANES) {
+            unsigned w[3] = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), 0u};
+            store_terms(pl, row0 * LDPB, w);
+        }
+#else
+        if constexpr (TO_PLANES) {
+            unsigned w[3];
+            split2(v[0], v[1], w);
+            store_terms(pl, row0 * LDPB, w);
+        }
+#endif
+    }
     if constexpr (MODE == 1) {
-        if (mask_out) *mask_out = ((unsigned long long)mhi << 32) | mlo;
+        if (mask_out) *mask_out = mbits;
     }
 }
 
@@ -384,13 +423,13 @@ template <int WIDTH>
 __device__ __forceinline__ void x3_copy_stage(const unsigned char* stage0, float* __restrict__ g, int tid) {
     constexpr int C4 = WIDTH / 4;
 #pragma unroll
-    for (int i = tid; i < TR * C4; i += 256) {
+    for (int i = tid; i < TR * C4; i += X3_THREADS) {
         const int row = i / C4, c4 = i % C4;
         *reinterpret_cast<f32x4*>(g + (size_t)row * WIDTH + 4 * c4) = *reinterpret_cast<const f32x4*>(stage0 + row * LDPB + 16 * c4);
     }
 }
 
-__global__ __launch_bounds__(256, 1) void nerf_fwd_x3_kernel(X3FwdArgs a) {
+__global__ __launch_bounds__(X3_THREADS, 1) void nerf_fwd_x3_kernel(X3FwdArgs a) {
     using namespace lay;
     using namespace lay::nerf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
@@ -400,78 +439,95 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_x3_kernel(X3FwdArgs a) {
     float* sraw_s = xin + X3_XIN_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow0 = (wave >> 2) * 32, wcol = wave & 3;     // this wave's 32 rows and column group
+    const bool per_sample = tid < 256;                       // the four-threads-per-sample phases
     const size_t m0 = (size_t)blockIdx.x * TR;
     const float* __restrict__ pk = a.pk;
     const __bf16* __restrict__ xi = a.x3;
     float* ws = a.ws;
     const size_t Mp = a.Mp;
     auto wsp = [&](size_t off, int width) -> float* { return ws + off * Mp + m0 * width; };
-    auto mskp = [&](int l) -> mask_t* { return reinterpret_cast<mask_t*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid; };
-    const int smp = tid / TPS, q = tid % TPS;
+    // this lane's ReLU mask word of layer l: 512 words per tile and layer (the footprint of the fp32 kernels' 256 x 64 bits)
+    auto mskp = [&](int l) -> xmask_t* { return reinterpret_cast<xmask_t*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid; };
+    const int smp = (tid & 255) / TPS, q = tid % TPS;
     // fp32 staging rows of the encodings: bytes 128.. of plane 0's rows (columns 64.. of a plane are unused while the
     // encoding is a layer's input)
     unsigned char* stage0 = planes + 128;
 
-    load_sincos_table(tab, tid);
+    if (per_sample) load_sincos_table(tab, tid);
     x3_load_inputs(a, m0, xin, tid);
+    const int ncol0 = wcol * 64;
+    X3Pre<2> pre;
+    x3_prefetch<2, PE_P / 16, ACC_BIAS>(xi + x3::F_L0, H, ncol0, lane, pk + BIAS, pre);
     __syncthreads();
     const auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
     const bool pe_fast = uniform(xin[6]) * 512.0f <= 9.9e4f;
     EncCache<10> pec;
-    if (pe_fast) {
-        enc_compute<10>(xin + smp * 8, q, pec);
-        x3_enc_store<10>(planes, reinterpret_cast<float*>(stage0 + smp * LDPB), smp, q, pec);
-    } else {
-        x3_enc_slow<10>(planes, reinterpret_cast<float*>(stage0 + smp * LDPB), smp, q, xin + smp * 8);
+    if (per_sample) {
+        if (pe_fast) {
+            enc_compute<10>(xin + smp * 8, q, pec);
+            x3_enc_store<10>(planes, reinterpret_cast<float*>(stage0 + smp * LDPB), smp, q, pec);
+        } else {
+            x3_enc_slow<10>(planes, reinterpret_cast<float*>(stage0 + smp * LDPB), smp, q, xin + smp * 8);
+        }
     }
     __syncthreads();
     x3_copy_stage<PE_P>(stage0, wsp(WS_PE, PE_P), tid);
 
-    const int ncol0 = wave * 64;
-    f32x16 acc[MT][2];
-    // L0
-    mma_layer_x3<2, PE_P / 16, ACC_BIAS>(planes, xi + x3::F_L0, H, ncol0, lane, acc, pk + BIAS);
+    f32x16 acc[2];
+    constexpr size_t EHH = x3::elems(H, H);
+    // L0 (its first weight fragments were requested before the encoding)
+    mma_layer_x3<2, PE_P / 16, ACC_BIAS>(planes, xi + x3::F_L0, H, ncol0, wrow0, lane, acc, pre);
+    x3_prefetch<2, H / 16, ACC_BIAS>(xi + x3::F_L1, H, ncol0, lane, pk + BIAS + H, pre);
     __syncthreads();
-    x3_epilogue<1, true>(planes, acc, ncol0, lane, wsp(WS_H, H), mskp(0), 0, nullptr, nullptr);
+    x3_epilogue<1, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_H, H), mskp(0), 0, nullptr, nullptr);
     __syncthreads();
+    static_assert(x3::F_L5A == x3::F_L1 + 4 * EHH && x3::F_L9 == x3::F_L6 + 3 * EHH, "the next layer's image follows");
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
-        mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L1 + (size_t)(l - 1) * x3::elems(H, H), H, ncol0, lane, acc,
-                                          pk + BIAS + l * H);
+        mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L1 + (size_t)(l - 1) * EHH, H, ncol0, wrow0, lane, acc, pre);
+        x3_prefetch<2, H / 16, ACC_BIAS>(xi + x3::F_L1 + (size_t)l * EHH, H, ncol0, lane, pk + BIAS + (l + 1) * H, pre);   // L(l+1), L5A after L4
         __syncthreads();
-        x3_epilogue<1, true>(planes, acc, ncol0, lane, wsp(WS_H + (size_t)l * H, H), mskp(l), 0, nullptr, nullptr);
+        x3_epilogue<1, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_H + (size_t)l * H, H), mskp(l), 0, nullptr, nullptr);
         __syncthreads();
     }
     // L5: [h4 | pe]
-    mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L5A, H, ncol0, lane, acc, pk + BIAS + 5 * H);
+    mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L5A, H, ncol0, wrow0, lane, acc, pre);
+    x3_prefetch<2, PE_P / 16, ACC_KEEP>(xi + x3::F_L5B, H, ncol0, lane, nullptr, pre);
     __syncthreads();
-    if (pe_fast) x3_enc_store<10>(planes, nullptr, smp, q, pec);
-    else x3_enc_slow<10>(planes, nullptr, smp, q, xin + smp * 8);
+    if (per_sample) {
+        if (pe_fast) x3_enc_store<10>(planes, nullptr, smp, q, pec);
+        else x3_enc_slow<10>(planes, nullptr, smp, q, xin + smp * 8);
+    }
     __syncthreads();
-    mma_layer_x3<2, PE_P / 16, ACC_KEEP>(planes, xi + x3::F_L5B, H, ncol0, lane, acc);
+    mma_layer_x3<2, PE_P / 16, ACC_KEEP>(planes, xi + x3::F_L5B, H, ncol0, wrow0, lane, acc, pre);
+    x3_prefetch<2, H / 16, ACC_BIAS>(xi + x3::F_L6, H, ncol0, lane, pk + BIAS + 6 * H, pre);
     __syncthreads();
-    x3_epilogue<1, true>(planes, acc, ncol0, lane, wsp(WS_H + 5 * (size_t)H, H), mskp(5), 0, nullptr, nullptr);
+    x3_epilogue<1, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_H + 5 * (size_t)H, H), mskp(5), 0, nullptr, nullptr);
     __syncthreads();
 #pragma unroll 1
     for (int l = 6; l <= 8; ++l) {
-        mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L6 + (size_t)(l - 6) * x3::elems(H, H), H, ncol0, lane, acc,
-                                          pk + BIAS + l * H);
+        mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L6 + (size_t)(l - 6) * EHH, H, ncol0, wrow0, lane, acc, pre);
+        x3_prefetch<2, H / 16, ACC_BIAS>(xi + x3::F_L6 + (size_t)(l - 5) * EHH, H, ncol0, lane, pk + BIAS + (l + 1) * H, pre);   // L9 after L8
         __syncthreads();
-        x3_epilogue<1, true>(planes, acc, ncol0, lane, wsp(WS_H + (size_t)l * H, H), mskp(l), 0, nullptr, nullptr);
+        x3_epilogue<1, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_H + (size_t)l * H, H), mskp(l), 0, nullptr, nullptr);
         __syncthreads();
     }
     // L9: 256 feature columns on MFMA; the density row is a dot product of h8 with the 257th weight row, taken from
     // the fp32 copy of h8 that the epilogue above has just written to the workspace (the planes hold it as bf16 terms)
-    mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L9, H, ncol0, lane, acc, pk + BIAS + 9 * H);
-    {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // every wave's h8 stores are complete (they bypass no cache this workgroup reads through)
+    mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L9, H, ncol0, wrow0, lane, acc, pre);
+    const int nc = wcol * 32;
+    X3Pre<1> pre1;
+    x3_prefetch<1, H / 16, ACC_BIAS>(xi + x3::F_L10A, HH, nc, lane, pk + BIAS10, pre1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // every wave's h8 stores are complete; the planes are free
+    if (per_sample) {
         const float* h8 = wsp(WS_H + 8 * (size_t)H, H) + (size_t)smp * H;
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int k = 4 * (TPS * i + q);
-            const f32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h8 + k));
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(h8 + k);
             const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + SIGW + k);
             s += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
         }
@@ -483,64 +539,66 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_x3_kernel(X3FwdArgs a) {
             ws[WS_SRAW * Mp + m0 + smp] = s;
         }
     }
-    x3_epilogue<0, true>(planes, acc, ncol0, lane, wsp(WS_F, H), nullptr, 0, nullptr, nullptr);
+    x3_epilogue<0, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_F, H), nullptr, 0, nullptr, nullptr);
     __syncthreads();
     // L10: [f | de] -> 128, ReLU
     {
-        const int nc = wave * 32;
-        f32x16 acc1[MT][1];
-        mma_layer_x3<1, H / 16, ACC_BIAS>(planes, xi + x3::F_L10A, HH, nc, lane, acc1, pk + BIAS10);
+        f32x16 acc1[1];
+        mma_layer_x3<1, H / 16, ACC_BIAS>(planes, xi + x3::F_L10A, HH, nc, wrow0, lane, acc1, pre1);
+        x3_prefetch<1, DE_P / 16, ACC_KEEP>(xi + x3::F_L10B, HH, nc, lane, nullptr, pre1);
         __syncthreads();
         unsigned char* stage_de = planes + 128;   // columns 64.. are free: the direction encoding is 32 wide
         float* st = reinterpret_cast<float*>(stage_de + smp * LDPB);
-        if (uniform(xin[7]) * 8.0f <= 9.9e4f) {
-            EncCache<4> dec;
-            enc_compute<4>(xin + smp * 8 + 3, q, dec);
-            x3_enc_store<4>(planes, st, smp, q, dec);
-        } else {
-            x3_enc_slow<4>(planes, st, smp, q, xin + smp * 8 + 3);
+        if (per_sample) {
+            if (uniform(xin[7]) * 8.0f <= 9.9e4f) {
+                EncCache<4> dec;
+                enc_compute<4>(xin + smp * 8 + 3, q, dec);
+                x3_enc_store<4>(planes, st, smp, q, dec);
+            } else {
+                x3_enc_slow<4>(planes, st, smp, q, xin + smp * 8 + 3);
+            }
         }
         __syncthreads();
         x3_copy_stage<DE_P>(stage_de, wsp(WS_DE, DE_P), tid);
-        mma_layer_x3<1, DE_P / 16, ACC_KEEP>(planes, xi + x3::F_L10B, HH, nc, lane, acc1);
+        mma_layer_x3<1, DE_P / 16, ACC_KEEP>(planes, xi + x3::F_L10B, HH, nc, wrow0, lane, acc1, pre1);
         __syncthreads();
         // epilogue: g = max(0, -n) as fp32 into the plane area (viewed as [64][LDG] floats) for the head, and to the workspace
         float* gt = reinterpret_cast<float*>(planes);
         float* gg = wsp(WS_G, HH);
         const int col = nc + (lane & 31);
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int row = acc_row(mi, g, lane);
-                float v = acc1[mi][0][g];
-                asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v) : "v"(v));
-                gt[row * LDG + col] = v;
-                gg[(size_t)row * HH + col] = v;
-            }
+        for (int g = 0; g < 16; ++g) {
+            const int row = wrow0 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+            float v = acc1[0][g];
+            asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v) : "v"(v));
+            gt[row * LDG + col] = v;
+            gg[(size_t)row * HH + col] = v;
+        }
         __syncthreads();
         // L11 + sigmoid, density = relu(raw)
-        float z[3] = {0.f, 0.f, 0.f};
+        if (per_sample) {
+            float z[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = 4 * (TPS * i + q);
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(gt + smp * LDG + k);
+            for (int i = 0; i < 8; ++i) {
+                const int k = 4 * (TPS * i + q);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(gt + smp * LDG + k);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + W11 + c * HH + k);
+                    z[c] += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + W11 + c * HH + k);
-                z[c] += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
+                z[c] += __shfl_xor(z[c], 1);
+                z[c] += __shfl_xor(z[c], 2);
             }
-        }
+            const size_t m = m0 + smp;
+            if (q == 0 && m < (size_t)a.M) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            z[c] += __shfl_xor(z[c], 1);
-            z[c] += __shfl_xor(z[c], 2);
-        }
-        const size_t m = m0 + smp;
-        if (q == 0 && m < (size_t)a.M) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) a.colors[m * 3 + c] = sigmoidf_(z[c] + pk[BIAS11 + c]);
-            a.density[m] = fmaxf(sraw_s[smp], 0.0f);
+                for (int c = 0; c < 3; ++c) a.colors[m * 3 + c] = sigmoidf_(z[c] + pk[BIAS11 + c]);
+                a.density[m] = fmaxf(sraw_s[smp], 0.0f);
+            }
         }
     }
 }
@@ -558,7 +616,7 @@ struct X3BwdArgs {
     float* bw;
 };
 
-__global__ __launch_bounds__(256, 1) void nerf_dgrad_x3_kernel(X3BwdArgs a) {
+__global__ __launch_bounds__(X3_THREADS, 1) void nerf_dgrad_x3_kernel(X3BwdArgs a) {
     using namespace lay;
     using namespace lay::nerf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
@@ -566,18 +624,21 @@ __global__ __launch_bounds__(256, 1) void nerf_dgrad_x3_kernel(X3BwdArgs a) {
     float* dsig_s = reinterpret_cast<float*>(planes + PLANES_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow0 = (wave >> 2) * 32, wcol = wave & 3;
     const size_t m0 = (size_t)blockIdx.x * TR;
     const size_t Mp = a.Mp;
     const float* __restrict__ pk = a.pk;
     const __bf16* __restrict__ xi = a.x3;
     const float* ws = a.ws;
     float* bw = a.bw;
-    const int ncol0 = wave * 64;
+    const int ncol0 = wcol * 64;
     auto dzp = [&](int l) { return bw + (BW_DZ + (size_t)l * H) * Mp + m0 * H; };
-    auto mskp = [&](int l) { return reinterpret_cast<const mask_t*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid; };
+    auto mskp = [&](int l) { return reinterpret_cast<const xmask_t*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid; };
 
+    X3Pre<2> pre;
+    x3_prefetch<2, HH / 16, ACC_ZERO>(xi + x3::D10, H, ncol0, lane, nullptr, pre);
     // gradient of the 128 -> 3 sigmoid head (head_bwd of mlp_bwd.hip), its result dz10 [64][128] into the planes
-    {
+    if (tid < 256) {
         const int smp = tid / TPS, q = tid % TPS;
         const size_t m = m0 + smp;
         float dz[3] = {0.f, 0.f, 0.f};
@@ -622,32 +683,35 @@ __global__ __launch_bounds__(256, 1) void nerf_dgrad_x3_kernel(X3BwdArgs a) {
         }
     }
     __syncthreads();
-    f32x16 acc[MT][2];
+    f32x16 acc[2];
     // rgb_head.0 (feature part): reduce over its 128 outputs -> dz9, the gradient of the 256 features
-    mma_layer_x3<2, HH / 16, ACC_ZERO>(planes, xi + x3::D10, H, ncol0, lane, acc);
+    mma_layer_x3<2, HH / 16, ACC_ZERO>(planes, xi + x3::D10, H, ncol0, wrow0, lane, acc, pre);
+    x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3::d_img(9), H, ncol0, lane, nullptr, pre);
     __syncthreads();
-    x3_epilogue<4, true>(planes, acc, ncol0, lane, bw + BW_DZ9 * Mp + m0 * H, nullptr, 0, nullptr, nullptr);
+    x3_epilogue<4, true>(planes, acc, ncol0, wrow0, lane, bw + BW_DZ9 * Mp + m0 * H, nullptr, 0, nullptr, nullptr);
     __syncthreads();
     // block2.8: feature rows on MFMA + the density row as a rank-1 term, ReLU mask of h8 -> dz8
     {
-        const mask_t bits = *mskp(8);
-        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(9), H, ncol0, lane, acc);
+        const xmask_t bits = *mskp(8);
+        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(9), H, ncol0, wrow0, lane, acc, pre);
+        x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3::d_img(8), H, ncol0, lane, nullptr, pre);
         __syncthreads();
-        x3_epilogue<3, true>(planes, acc, ncol0, lane, dzp(8), nullptr, bits, dsig_s, pk + SIGW);
+        x3_epilogue<3, true>(planes, acc, ncol0, wrow0, lane, dzp(8), nullptr, bits, dsig_s, pk + SIGW);
         __syncthreads();
     }
 #pragma unroll 1
     for (int l = 8; l >= 2; --l) {
-        const mask_t bits = *mskp(l - 1);
-        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(l), H, ncol0, lane, acc);
+        const xmask_t bits = *mskp(l - 1);
+        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(l), H, ncol0, wrow0, lane, acc, pre);
+        x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3::d_img(l - 1), H, ncol0, lane, nullptr, pre);
         __syncthreads();
-        x3_epilogue<2, true>(planes, acc, ncol0, lane, dzp(l - 1), nullptr, bits, nullptr, nullptr);
+        x3_epilogue<2, true>(planes, acc, ncol0, wrow0, lane, dzp(l - 1), nullptr, bits, nullptr, nullptr);
         __syncthreads();
     }
     {
-        const mask_t bits = *mskp(0);
-        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(1), H, ncol0, lane, acc);
-        x3_epilogue<2, false>(planes, acc, ncol0, lane, dzp(0), nullptr, bits, nullptr, nullptr);
+        const xmask_t bits = *mskp(0);
+        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(1), H, ncol0, wrow0, lane, acc, pre);
+        x3_epilogue<2, false>(planes, acc, ncol0, wrow0, lane, dzp(0), nullptr, bits, nullptr, nullptr);
     }
 }
 
@@ -710,7 +774,7 @@ extern "C" int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const 
                 t, S, t_per_ray, (float)near, (float)(far - near), colors, density, workspace};
     int rc;
     if ((rc = nerf_set_lds(nerf_fwd_x3_kernel, X3_FWD_LDS_BYTES))) return rc;
-    nerf_fwd_x3_kernel<<<(unsigned)tiles, 256, X3_FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    nerf_fwd_x3_kernel<<<(unsigned)tiles, X3_THREADS, X3_FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
     return nerf_check_launch("nerf_mlp_fwd_x3");
 }
 
@@ -730,6 +794,6 @@ extern "C" int nerf_mlp_bwd_data_x3(int model, const float* packed, int64_t M, c
                 fwd_workspace, bwd_workspace};
     int rc;
     if ((rc = nerf_set_lds(nerf_dgrad_x3_kernel, X3_BWD_LDS_BYTES))) return rc;
-    nerf_dgrad_x3_kernel<<<(unsigned)(Mp / TR), 256, X3_BWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    nerf_dgrad_x3_kernel<<<(unsigned)(Mp / TR), X3_THREADS, X3_BWD_LDS_BYTES, (hipStream_t)stream>>>(a);
     return nerf_check_launch("nerf_mlp_bwd_data_x3");
 }
