@@ -337,6 +337,8 @@ def main():
                      ("mlp_fwd_train_x3", 6 * fl["fwd"], "bf16x3 opt-in: the training forward with every fp32 operand as three bf16 "
                                                          "terms; matrix-pipe flops = 6 term products per product of the fp32 algorithm"),
                      ("mlp_bwd_data_x3", 6 * fl["dgrad"], "bf16x3 opt-in: the data-gradient chain, same arithmetic"),
+                     ("mlp_bwd_weights_x3", 6 * fl["wgrad"], "bf16x3 opt-in: weight-gradient launch group, wide products with three-term "
+                                                             "operands (flops counted as 6 term products throughout; the narrow products run on fp32 MFMA)"),
                      ("mlp_bwd_weights", fl["wgrad"], "per-layer weight-gradient GEMMs + one reduction (launch group)")]
         else:
             specs = [("mlp_fwd_infer", fl["fwd"], "fused sample+encode+MLP forward (inference)"),
@@ -387,7 +389,7 @@ def main():
         # single kernel of the step; the weight-gradient entry is a launch group.
         alone = {}
         for name, k in kernels.items():
-            if k.get("concurrent") or name.startswith("mlp_bwd_weights"):
+            if k.get("concurrent") or name.startswith("mlp_bwd_weights"):   # (also mlp_bwd_weights_x3)
                 continue
             m = alone.setdefault(name.split("@")[0], {"n": 0.0, "ms": 0.0, "flop": 0.0, "per_sample": k["flop_per_sample"]})
             m["n"] += k["launches_per_step"]
@@ -417,7 +419,7 @@ def main():
                             + (f", the {args.coarse} coarse ones density only)" if hier else ")")),
             "value": world * B * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16x3 (forward, data gradient) + f32 (weight gradient)" if args.train_precision == "bf16x3"
+            "vs_baseline": None, "dtype": "bf16x3" if args.train_precision == "bf16x3"
             else {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
             "config": {"workload": f"lego-shaped synthetic {args.res}x{args.res} scene, {B} rays/GPU/step, "
                                    + (f"{args.coarse} coarse + ({args.coarse}+{args.fine}) fine = {S} MLP evaluations/ray, "
@@ -425,7 +427,7 @@ def main():
                                       f"{S} samples/ray single pass, one {args.model} MLP")
                                    + {"fp32": " (fp32 MFMA)", "bf16": " (bf16 MFMA, fp32 accumulate)",
                                       "bf16x3": " (fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate)"}[args.precision]
-                                   + (" -- opt-in training mode: forward and data gradient as three bf16 terms per operand, weight gradient fp32 MFMA"
+                                   + (" -- opt-in training mode: every fp32 operand as three bf16 terms on the bf16 matrix pipe (narrow weight-gradient products on fp32 MFMA)"
                                       if args.train_precision == "bf16x3" else "") + f", {args.mode}", "network": args.model, "sampling": args.sampling,
                        "rays_per_gpu": B, "rays_per_step": B * world, "mlp_evals_per_ray": S,
                        "parallelism": f"dp{world} ray-sharded, flat-bucket RCCL all-reduce" if world > 1 else "single GPU"},

@@ -187,7 +187,7 @@ int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_workspace, float
  * nerf_mlp_pack_x3: the fp32 image of nerf_mlp_pack (so the same pointer also serves nerf_mlp_fwd without a
  * workspace) followed by the three-term planes of every dense layer, forward and transposed.  A workspace written
  * by nerf_mlp_fwd_x3 must be read by nerf_mlp_bwd_data_x3 (its ReLU mask words follow this mode's accumulator
- * columns); nerf_mlp_bwd_weights then runs unchanged on both workspaces. */
+ * columns); nerf_mlp_bwd_weights, or its three-term variant below, then runs on either workspace. */
 size_t nerf_mlp_packed_x3_floats(int model);                   /* 0 for a model without this mode */
 int nerf_mlp_pack_x3(int model, const float* const* params, float* packed, void* stream);
 int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const float* points, const float* dirs,
@@ -195,6 +195,11 @@ int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const float* poin
                     double far, float* colors, float* density, float* workspace, void* stream);
 int nerf_mlp_bwd_data_x3(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
                          const float* colors, const float* fwd_workspace, float* bwd_workspace, void* stream);
+/* nerf_mlp_bwd_weights with its wide products (the nine 256 x 256 layers and the 128 x 256 one: 95 % of the flops) on
+ * the bf16 matrix pipe, operands split into three bf16 terms while they are staged; the narrow products, the partial
+ * slabs and the ordered reduction are those of nerf_mlp_bwd_weights.  Reads either kind of workspace. */
+int nerf_mlp_bwd_weights_x3(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
+                            int accumulate, void* stream);
 
 /* ---- layer-wise dense path for the other architectures the reference's constructors accept
  * (nerf/models.py:18-60 NeRF(pos_encoding_dim, dir_encoding_dim, hidden_dim), :148-183 Siren(...)):

@@ -356,6 +356,171 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+
+// ---- weight gradient on the bf16 matrix pipe (opt-in bf16x3 training mode) --------------------------------------
+// Same product, same partial slabs and reduction as wgrad_kernel, with the arithmetic of mlp_x3.hip: every fp32 value
+// of dY and X is split into three bf16 terms and a product is formed from six exact term products accumulated in
+// fp32 (v_mfma_f32_32x32x16_bf16 contracts 16 samples per instruction).  The MFMA wants the contraction index
+// contiguous per lane -- 8 consecutive SAMPLES of one feature -- while the workspace rows are samples.  The transposition
+// rides on the split: a thread loads 8 samples x 4 adjacent features of a 32-sample chunk (eight 16-byte loads, a wave
+// covers whole 1 KiB rows), splits its 32 values (each pair of consecutive samples gives one packed bf16 pair per
+// term), and writes for each of its 4 features and 3 terms ONE 16-byte piece = 8 consecutive samples into the LDS
+// image [term][feature][32 samples] (row pitch 80 bytes: the fragment reads of 16 consecutive features fall on 64
+// distinct banks).  Every value is split once per workgroup, not once per wave.  The chunk after next is loaded into
+// registers while the MFMAs of the current one run.  Bias column sums and the rank-1 row (density) are taken from the
+// fp32 registers on the way.  8 waves as 2 x 4: wave (wn, wk) owns rows [wn*NW/2, +NW/2) x columns [wk*64, +64).
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
+constexpr int WX3_PITCH = 80;    // bytes per feature row of a term plane: 32 samples of bf16 + 16
+
+template <int NW, int KW>
+constexpr int wgrad_x3_lds_bytes() { return 3 * (NW + KW) * WX3_PITCH; }
+
+__device__ __forceinline__ unsigned wx3_pack2(float lo, float hi) {
+    typedef float wf32x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((wf32x2){lo, hi}, wbf16x2));
+}
+__device__ __forceinline__ void wx3_split2(float v0, float v1, unsigned (&w)[3]) {
+#pragma clang fp contract(off)
+    w[0] = wx3_pack2(v0, v1);
+#pragma unroll
+    for (int p = 1; p < 3; ++p) {
+        v0 -= __builtin_bit_cast(float, w[p - 1] << 16);           // exact
+        v1 -= __builtin_bit_cast(float, w[p - 1] & 0xffff0000u);
+        w[p] = wx3_pack2(v0, v1);
+    }
+}
+
+template <int NW, int KW, bool RANK1>
+__global__ __launch_bounds__(512, 1) void wgrad_x3_kernel(WgradArgs a) {
+    static_assert(KW == 256 && (NW == 256 || NW == 128), "shapes of the wide layers");
+    constexpr int TN = NW / 2 / 32, TK = KW / 4 / 32;      // 32 x 32 tiles per wave: TN x 2
+    constexpr int F = NW + KW, NQ = F / 4;                 // staged features per sample; feature quads
+    constexpr int PLANE = F * WX3_PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int c0 = (int)((int64_t)a.nchunks * bid / G), c1 = (int)((int64_t)a.nchunks * (bid + 1) / G);
+    const int wn = wave >> 2, wk = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    // staging role: sample octet `so` and feature quad `fq` (quads below NW/4 belong to dY, the rest to X)
+    const bool stager = tid < 4 * NQ;
+    const int so = tid / NQ, fq = tid % NQ;
+    const bool is_y = fq < NW / 4;
+    const float* src = is_y ? a.dY + 4 * fq : a.X + 4 * (fq - NW / 4);
+    const int ld = is_y ? a.ldy : a.ldx;
+
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = splat16(0.0f);
+    f32x4 colsum = {0.f, 0.f, 0.f, 0.f};   // dY quads: column sums (bias gradient); X quads: sum_m q[m] X[m][:]
+    float qsum = 0.0f;
+
+    f32x4 v[8];
+    auto load_chunk = [&](int c) {
+        if (stager) {
+            const float* p = src + ((size_t)c * 32 + 8 * so) * ld;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x4*>(p + (size_t)e * ld);
+        }
+    };
+    if (c0 < c1) load_chunk(c0);
+    for (int c = c0; c < c1; ++c) {
+        // ---- split this thread's 8 samples x 4 features and publish them
+        if (stager) {
+            if (is_y) {
+                if (a.bslab) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) colsum += v[e];
+                }
+            } else if constexpr (RANK1) {
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(a.q + (size_t)c * 32 + 8 * so);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(a.q + (size_t)c * 32 + 8 * so + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float qe = e < 4 ? q0[e] : q1[e - 4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) colsum[i] = fmaf(qe, v[e][i], colsum[i]);
+                    qsum += qe;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wu32x4 piece[3];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    unsigned w[3];
+                    wx3_split2(v[2 * e2][i], v[2 * e2 + 1][i], w);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) piece[p][e2] = w[p];
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<wu32x4*>(wsm + p * PLANE + (4 * fq + i) * WX3_PITCH + 16 * so) = piece[p];
+            }
+        }
+        if (c + 1 < c1) load_chunk(c + 1);     // in flight during the MFMAs below
+        __syncthreads();
+        // ---- 2 k-steps of 16 samples: six term products per tile pair
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            wbf16x8 A[TN][3], B[TK][3];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    A[i][p] = *reinterpret_cast<const wbf16x8*>(wsm + p * PLANE + (wn * (NW / 2) + 32 * i + r) * WX3_PITCH + 32 * ks + 16 * h);
+#pragma unroll
+            for (int j = 0; j < TK; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    B[j][p] = *reinterpret_cast<const wbf16x8*>(wsm + p * PLANE + (NW + wk * (KW / 4) + 32 * j + r) * WX3_PITCH + 32 * ks + 16 * h);
+            constexpr int TA[6] = {0, 0, 0, 1, 1, 2}, TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TK; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][TA[t]], B[j][TB[t]], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- partial slab of this workgroup
+    {
+        float* out = a.slab + (size_t)bid * NW * KW;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TK; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int row = wn * (NW / 2) + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    out[(size_t)row * KW + wk * (KW / 4) + 32 * j + r] = acc[i][j][g];
+                }
+    }
+    // column sums: the four sample octets of a feature quad through LDS (the planes are free after the last barrier)
+    float* red = reinterpret_cast<float*>(wsm);       // [4][F] floats + 4
+    if (stager) *reinterpret_cast<f32x4*>(red + so * F + 4 * fq) = colsum;
+    if (RANK1 && stager && fq == NW / 4) red[4 * F + so] = qsum;
+    __syncthreads();
+    if (tid < F) {
+        const float t = (red[tid] + red[F + tid]) + (red[2 * F + tid] + red[3 * F + tid]);
+        if (tid < NW) {
+            if (a.bslab) a.bslab[(size_t)bid * NW + tid] = t;
+        } else if constexpr (RANK1) {
+            a.qslab[(size_t)bid * KW + tid - NW] = t;
+        }
+    }
+    if constexpr (RANK1) {
+        if (tid == 0) a.qbslab[(size_t)bid * 4] = (red[4 * F] + red[4 * F + 1]) + (red[4 * F + 2] + red[4 * F + 3]);
+    }
+}
+
 // thin products on the VALU: slab[g][b][a] = sum_m P[m][a] * Q[m][b], a < AW (128 or 256), b < NB <= 4,
 // Q stored [Mp][4].  Optional column sums of P (wide bias) and of Q (thin bias).
 // A thread owns 4 adjacent columns of P (16-byte loads, a whole row per 32 or 64 threads) and every
@@ -553,6 +718,31 @@ void wgrad(Ctx& c, const float* dY, int ldy, const float* X, int ldx, float* dW,
     }
 }
 
+// the same product on the bf16 matrix pipe (wgrad_x3_kernel): same slabs, same reduction jobs
+template <int NW, int KW, bool RANK1 = false>
+void wgrad_x3(Ctx& c, const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int kvalid, float* db,
+              const float* q = nullptr, float* qrow = nullptr, float* qbias = nullptr) {
+    if (c.rc) return;
+    const int nchunks = (int)(c.Mp / 32);
+    const int G = nchunks < lay::WG_MAX ? nchunks : lay::WG_MAX;
+    float* wslab = c.take(G, NW * KW);
+    float* bslab = db ? c.take(G, NW) : nullptr;
+    float* qslab = RANK1 ? c.take(G, KW) : nullptr;
+    float* qbslab = RANK1 ? c.take(G, 4) : nullptr;
+    if (c.rc) return;
+    WgradArgs a{dY, X, ldy, ldx, nchunks, wslab, bslab, q, qslab, qbslab};
+    auto kern = wgrad_x3_kernel<NW, KW, RANK1>;
+    if ((c.rc = nerf_set_lds(kern, wgrad_x3_lds_bytes<NW, KW>()))) return;
+    kern<<<G, 512, wgrad_x3_lds_bytes<NW, KW>(), c.st>>>(a);
+    if ((c.rc = nerf_check_launch("wgrad_x3"))) return;
+    reduce(c, wslab, G, NW, KW, kvalid, dW, ldw, 1);
+    if (db) reduce(c, bslab, G, 1, NW, NW, db, 0, 1);
+    if (RANK1) {
+        reduce(c, qslab, G, 1, KW, kvalid, qrow, 0, 1);
+        reduce(c, qbslab, G, 1, 4, 1, qbias, 0, 1);
+    }
+}
+
 // out[a*sa + b*sb] = sum_m P[m][a] Q[m][b] (Q stored [Mp][4]); optional db_wide[a] = sum_m P[m][a],
 // db_thin[b] = sum_m Q[m][b]
 void thin(Ctx& c, const float* P, int ldp, int AW, const float* Q, int NB, float* out, int sa, int sb, float* db_wide,
@@ -610,8 +800,24 @@ extern "C" int nerf_mlp_bwd_data(int model, const float* packed, int64_t M, cons
     return nerf_check_launch("nerf_mlp_bwd_data");
 }
 
+static int bwd_weights_impl(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads, int accumulate,
+                            void* stream, bool x3);
+
 extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
                                     int accumulate, void* stream) {
+    return bwd_weights_impl(model, M, fwd_workspace, bwd_workspace, grads, accumulate, stream, false);
+}
+
+// the wide products (256 x 256, 128 x 256: 95 % of the flops) on the bf16 matrix pipe with three-term operands; the
+// narrow ones and the reduction as in nerf_mlp_bwd_weights
+extern "C" int nerf_mlp_bwd_weights_x3(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
+                                       int accumulate, void* stream) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_bwd_weights_x3: the bf16x3 training mode covers the NeRF model only (model %d)", model);
+    return bwd_weights_impl(model, M, fwd_workspace, bwd_workspace, grads, accumulate, stream, true);
+}
+
+static int bwd_weights_impl(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads, int accumulate,
+                            void* stream, bool x3) {
     using namespace lay;
     int rc;
     if ((rc = bwd_check_args("nerf_mlp_bwd_weights", model, grads, M, fwd_workspace, bwd_workspace))) return rc;
@@ -630,15 +836,25 @@ extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_works
         auto dz = [&](int l) { return bw + (BW_DZ + (size_t)l * H) * Mp; };
         const float* pe = ws + WS_PE * Mp;
         const float* de = ws + WS_DE * Mp;
+        // the wide products: fp32 MFMA, or the bf16 matrix pipe in the bf16x3 training mode
+        auto wide = [&](const float* dY, const float* X, float* dW, int ldw, float* db) {
+            if (x3) wgrad_x3<256, 256>(c, dY, H, X, H, dW, ldw, H, db);
+            else wgrad<256, 256, 2, 4>(c, dY, H, X, H, dW, ldw, H, db);
+        };
         wgrad<256, 64, 8, 1>(c, dz(0), H, pe, PE_P, W(0), PE, PE, B(0));
-        for (int l = 1; l <= 4; ++l) wgrad<256, 256, 2, 4>(c, dz(l), H, h(l - 1), H, W(l), H, H, B(l));
-        wgrad<256, 256, 2, 4>(c, dz(5), H, h(4), H, W(5), H + PE, H, B(5));
+        for (int l = 1; l <= 4; ++l) wide(dz(l), h(l - 1), W(l), H, B(l));
+        wide(dz(5), h(4), W(5), H + PE, B(5));
         wgrad<256, 64, 8, 1>(c, dz(5), H, pe, PE_P, W(5) + H, H + PE, PE, nullptr);
-        for (int l = 6; l <= 8; ++l) wgrad<256, 256, 2, 4>(c, dz(l), H, h(l - 1), H, W(l), H, H, B(l));
+        for (int l = 6; l <= 8; ++l) wide(dz(l), h(l - 1), W(l), H, B(l));
         // block2.8: rows 0..255 from dz9, row 256 (density) is the rank-1 product of dsig with the same h8
-        wgrad<256, 256, 2, 4, true>(c, bw + BW_DZ9 * Mp, H, h(8), H, W(9), H, H, B(9), bw + BW_DSIG * Mp,
-                                    W(9) + (size_t)H * H, B(9) + H);
-        wgrad<128, 256, 2, 4>(c, bw + BW_DZ10 * Mp, HH, ws + WS_F * Mp, H, W(10), H + DE, H, B(10));
+        if (x3)
+            wgrad_x3<256, 256, true>(c, bw + BW_DZ9 * Mp, H, h(8), H, W(9), H, H, B(9), bw + BW_DSIG * Mp,
+                                     W(9) + (size_t)H * H, B(9) + H);
+        else
+            wgrad<256, 256, 2, 4, true>(c, bw + BW_DZ9 * Mp, H, h(8), H, W(9), H, H, B(9), bw + BW_DSIG * Mp,
+                                        W(9) + (size_t)H * H, B(9) + H);
+        if (x3) wgrad_x3<128, 256>(c, bw + BW_DZ10 * Mp, HH, ws + WS_F * Mp, H, W(10), H + DE, H, B(10));
+        else wgrad<128, 256, 2, 4>(c, bw + BW_DZ10 * Mp, HH, ws + WS_F * Mp, H, W(10), H + DE, H, B(10));
         wgrad<128, 32, 4, 1>(c, bw + BW_DZ10 * Mp, HH, de, DE_P, W(10) + H, H + DE, DE, nullptr);
         thin(c, ws + WS_G * Mp, HH, HH, bw + BW_DZ11 * Mp, 3, W(11), 1, HH, nullptr, B(11));
         return reduce_all(c);

@@ -57,6 +57,7 @@ _SIGS = {
     "nerf_mlp_pack_x3": (c_int, [c_int, ctypes.POINTER(c_void_p), _P, _P]),
     "nerf_mlp_fwd_x3": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P, _P, _P, _P]),
     "nerf_mlp_bwd_data_x3": (c_int, [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P]),
+    "nerf_mlp_bwd_weights_x3": (c_int, [c_int, c_int64, _P, _P, _P, c_int, _P]),
     "nerf_linear_bwd_workspace_floats": (c_size_t, [c_int64, c_int, c_int]),
     "nerf_linear_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_double, c_double, _P, c_int64, _P, _P]),
     "nerf_linear_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_double, c_double, _P, c_int64, _P, c_int64, c_int,
@@ -376,9 +377,10 @@ def mlp_bwd(model: int, packed: torch.Tensor, M: int, dcolors, ddensity, colors,
         _dev(colors, "colors"), _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
         _stream()), "nerf_mlp_bwd_data_x3" if x3 else "nerf_mlp_bwd_data")
     timers.stop(ev)
-    ev = timers.start("mlp_bwd_weights", M)
-    _check(lib.nerf_mlp_bwd_weights(model, M, _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
-                                    _dev(grads, "grads"), int(bool(accumulate)), _stream()), "nerf_mlp_bwd_weights")
+    ev = timers.start("mlp_bwd_weights_x3" if x3 else "mlp_bwd_weights", M)
+    _check((lib.nerf_mlp_bwd_weights_x3 if x3 else lib.nerf_mlp_bwd_weights)(
+        model, M, _dev(ws, "fwd_workspace"), _dev(bw, "bwd_workspace"),
+        _dev(grads, "grads"), int(bool(accumulate)), _stream()), "nerf_mlp_bwd_weights_x3" if x3 else "nerf_mlp_bwd_weights")
     timers.stop(ev)
     return grads
 
