@@ -365,17 +365,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
 // rides on the split: a thread loads 8 samples x 4 adjacent features of a 32-sample chunk (eight 16-byte loads, a wave
 // covers whole 1 KiB rows), splits its 32 values (each pair of consecutive samples gives one packed bf16 pair per
 // term), and writes for each of its 4 features and 3 terms ONE 16-byte piece = 8 consecutive samples into the LDS
-// image [term][feature][32 samples] (row pitch 80 bytes: the fragment reads of 16 consecutive features fall on 64
-// distinct banks).  Every value is split once per workgroup, not once per wave.  The chunk after next is loaded into
+// image [term][feature][32 samples] (padded per feature quad, see WX3_QUAD_PITCH).  Every value is split once per workgroup, not once per wave.  The chunk after next is loaded into
 // registers while the MFMAs of the current one run.  Bias column sums and the rank-1 row (density) are taken from the
 // fp32 registers on the way.  8 waves as 2 x 4: wave (wn, wk) owns rows [wn*NW/2, +NW/2) x columns [wk*64, +64).
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
-constexpr int WX3_PITCH = 80;    // bytes per feature row of a term plane: 32 samples of bf16 + 16
+// A term plane in LDS: feature f's 32 samples (64 bytes) at (f / 4) * 272 + (f % 4) * 64 -- 16 bytes of padding per
+// feature QUAD.  The staging writes of 16 consecutive quads (one 16-byte piece each) and the fragment reads of 16
+// consecutive features then both fall on 64 distinct banks (measured with an 80-byte pitch per feature: the writes,
+// four features = 320 bytes apart, collided four ways and cost a fifth of the kernel's cycles).
+constexpr int WX3_QUAD_PITCH = 272;
+__device__ __forceinline__ constexpr int wx3_feat_off(int f) { return (f >> 2) * WX3_QUAD_PITCH + (f & 3) * 64; }
 
 template <int NW, int KW>
-constexpr int wgrad_x3_lds_bytes() { return 3 * (NW + KW) * WX3_PITCH; }
+constexpr int wgrad_x3_lds_bytes() { return 3 * (NW + KW) / 4 * WX3_QUAD_PITCH; }
 
 __device__ __forceinline__ unsigned wx3_pack2(float lo, float hi) {
     typedef float wf32x2 __attribute__((ext_vector_type(2)));
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_kernel(WgradArgs a) {
     static_assert(KW == 256 && (NW == 256 || NW == 128), "shapes of the wide layers");
     constexpr int TN = NW / 2 / 32, TK = KW / 4 / 32;      // 32 x 32 tiles per wave: TN x 2
     constexpr int F = NW + KW, NQ = F / 4;                 // staged features per sample; feature quads
-    constexpr int PLANE = F * WX3_PITCH;
+    constexpr int PLANE = F / 4 * WX3_QUAD_PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -405,12 +409,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_kernel(WgradArgs a) {
     const int c0 = (int)((int64_t)a.nchunks * bid / G), c1 = (int)((int64_t)a.nchunks * (bid + 1) / G);
     const int wn = wave >> 2, wk = wave & 3;
     const int r = lane & 31, h = lane >> 5;
-    // staging role: sample octet `so` and feature quad `fq` (quads below NW/4 belong to dY, the rest to X)
-    const bool stager = tid < 4 * NQ;
-    const int so = tid / NQ, fq = tid % NQ;
-    const bool is_y = fq < NW / 4;
-    const float* src = is_y ? a.dY + 4 * fq : a.X + 4 * (fq - NW / 4);
+    // staging role: the first NW threads (whole waves) stage dY, the next KW threads X; a thread owns one sample octet
+    // `so` of the chunk and one feature quad (`fq` counts quads over dY then X, the order of the LDS image)
+    const bool stager = wave < F / 64;
+    const bool is_y = wave < NW / 64;                       // wave-uniform: the buffer resources below stay scalar
+    const int tt = is_y ? tid : tid - NW;
+    const int nq = (is_y ? NW : KW) / 4;
+    const int so = tt / nq, fq = (is_y ? 0 : NW / 4) + tt % nq;
+    const float* src = is_y ? a.dY : a.X;
     const int ld = is_y ? a.ldy : a.ldx;
+    static_assert(NW % 64 == 0 && KW % 64 == 0 && NQ > 0, "whole waves per tensor");
 
     f32x16 acc[TN][TK];
 #pragma unroll
@@ -420,17 +428,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_kernel(WgradArgs a) {
     f32x4 colsum = {0.f, 0.f, 0.f, 0.f};   // dY quads: column sums (bias gradient); X quads: sum_m q[m] X[m][:]
     float qsum = 0.0f;
 
-    f32x4 v[8];
-    auto load_chunk = [&](int c) {
+    // Loads through a buffer resource covering this workgroup's rows: the thread's part of the address (its sample
+    // octet and feature quad) is one constant 32-bit offset, the chunk and the sample inside the octet advance in the
+    // scalar offset -- no vector address arithmetic per chunk.  One register set: the loads of the next chunk are issued
+    // right after the current one has been split out of it, and land during the MFMAs.
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(src + (size_t)c0 * 32 * ld, (unsigned)((size_t)(c1 - c0) * 32 * ld * 4));
+    const int voff = stager ? (8 * so * ld + 4 * (tt % nq)) * 4 : 0;
+    auto load_chunk = [&](int c, f32x4 (&v)[8]) {
         if (stager) {
-            const float* p = src + ((size_t)c * 32 + 8 * so) * ld;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x4*>(p + (size_t)e * ld);
+            for (int e = 0; e < 8; ++e)
+                v[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, ((c - c0) * 32 + e) * ld * 4, 0));
         }
     };
-    if (c0 < c1) load_chunk(c0);
-    for (int c = c0; c < c1; ++c) {
-        // ---- split this thread's 8 samples x 4 features and publish them
+    // split this thread's 8 samples x 4 features and publish them; bias / rank-1 sums on the way
+    auto publish = [&](int c, const f32x4 (&v)[8]) {
         if (stager) {
             if (is_y) {
                 if (a.bslab) {
@@ -460,12 +472,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_kernel(WgradArgs a) {
                 }
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<wu32x4*>(wsm + p * PLANE + (4 * fq + i) * WX3_PITCH + 16 * so) = piece[p];
+                    *reinterpret_cast<wu32x4*>(wsm + p * PLANE + fq * WX3_QUAD_PITCH + i * 64 + 16 * so) = piece[p];
             }
         }
-        if (c + 1 < c1) load_chunk(c + 1);     // in flight during the MFMAs below
-        __syncthreads();
-        // ---- 2 k-steps of 16 samples: six term products per tile pair
+    };
+    // 2 k-steps of 16 samples: six term products per tile pair
+    auto mfma_phase = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             wbf16x8 A[TN][3], B[TK][3];
@@ -473,12 +485,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_kernel(WgradArgs a) {
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    A[i][p] = *reinterpret_cast<const wbf16x8*>(wsm + p * PLANE + (wn * (NW / 2) + 32 * i + r) * WX3_PITCH + 32 * ks + 16 * h);
+                    A[i][p] = *reinterpret_cast<const wbf16x8*>(wsm + p * PLANE + wx3_feat_off(wn * (NW / 2) + 32 * i + r) + 32 * ks + 16 * h);
 #pragma unroll
             for (int j = 0; j < TK; ++j)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    B[j][p] = *reinterpret_cast<const wbf16x8*>(wsm + p * PLANE + (NW + wk * (KW / 4) + 32 * j + r) * WX3_PITCH + 32 * ks + 16 * h);
+                    B[j][p] = *reinterpret_cast<const wbf16x8*>(wsm + p * PLANE + wx3_feat_off(NW + wk * (KW / 4) + 32 * j + r) + 32 * ks + 16 * h);
             constexpr int TA[6] = {0, 0, 0, 1, 1, 2}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
             for (int t = 0; t < 6; ++t)
@@ -488,6 +500,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_kernel(WgradArgs a) {
                     for (int j = 0; j < TK; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][TA[t]], B[j][TB[t]], acc[i][j], 0, 0, 0);
         }
+    };
+    f32x4 v[8];
+    if (c0 < c1) load_chunk(c0, v);
+    for (int c = c0; c < c1; ++c) {
+        publish(c, v);
+        if (c + 1 < c1) load_chunk(c + 1, v);      // in flight during the MFMAs below
+        __syncthreads();
+        mfma_phase();
         __syncthreads();
     }
     // ---- partial slab of this workgroup
@@ -506,7 +526,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_kernel(WgradArgs a) {
     // column sums: the four sample octets of a feature quad through LDS (the planes are free after the last barrier)
     float* red = reinterpret_cast<float*>(wsm);       // [4][F] floats + 4
     if (stager) *reinterpret_cast<f32x4*>(red + so * F + 4 * fq) = colsum;
-    if (RANK1 && stager && fq == NW / 4) red[4 * F + so] = qsum;
+    if (RANK1 && stager && fq == NW / 4) red[4 * F + so] = qsum;    // (the first X quad of every sample octet)
     __syncthreads();
     if (tid < F) {
         const float t = (red[tid] + red[F + tid]) + (red[2 * F + tid] + red[3 * F + tid]);
