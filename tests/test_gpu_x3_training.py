@@ -81,3 +81,65 @@ def test_bf16x3_render_step_matches_oracle():
         torch.manual_seed(11)
         b = render_nerf(m32, o.to(DEV), d.to(DEV), 2.0, 6.0, num_samples=S, device=DEV)
     assert torch.equal(a, b)
+
+
+def test_bf16x3_training_is_reproducible_and_tracks_fp32_over_adam_steps():
+    """Coarse + fine pair, one bucket, fused Adam: two runs of the bf16x3 mode are bit-identical (the weight-gradient
+    partial slabs are summed in a fixed order, no atomics), and after 5 steps its parameters sit where the fp32
+    kernels put them, to rounding amplified by Adam (the bound the two-rank tests use: a fraction of the distance
+    travelled)."""
+    from nerf import parallel
+    from nerf.models import NeRF
+    from nerf.rendering import render_nerf_hierarchical
+    o, d = rays(512, 21)
+    o, d = o.to(DEV), d.to(DEV)
+    tgt = torch.rand(512, 3, generator=torch.Generator().manual_seed(22)).to(DEV)
+
+    def run(precision):
+        torch.manual_seed(3)
+        nets = torch.nn.ModuleDict({"coarse": NeRF(), "fine": NeRF()}).to(DEV)
+        for n in nets.values():
+            n.set_training_precision(precision)
+        flat = parallel.FlatParameters(nets)
+        start = flat.flat.clone()
+        opt = parallel.FusedAdam(flat, lr=5e-4)
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        losses = []
+        for _ in range(5):
+            u = torch.rand(32, device=DEV, generator=gen)
+            uf = torch.rand(512, 64, device=DEV, generator=gen)
+            opt.zero_grad()
+            rc, rf = render_nerf_hierarchical(nets["coarse"], nets["fine"], o, d, 2.0, 6.0, 32, 64, device=DEV, u=[u], u_fine=[uf])
+            loss = torch.nn.functional.mse_loss(rc, tgt) + torch.nn.functional.mse_loss(rf, tgt)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        return flat.flat.clone(), start, losses
+
+    p3a, start, l3 = run("bf16x3")
+    p3b, _, _ = run("bf16x3")
+    p32, _, l32 = run("fp32")
+    assert torch.equal(p3a, p3b)
+    moved = float((p32 - start).norm())
+    print("losses", l3, l32, "distance between modes / distance travelled", float((p3a - p32).norm()) / moved)
+    assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(l3[:2], l32[:2]))
+    assert float((p3a - p32).norm()) <= 2e-2 * moved
+
+
+def test_bf16x3_mode_is_nerf_only_and_switchable():
+    from nerf.models import NeRF, Siren
+    with pytest.raises(NotImplementedError):
+        Siren().to(DEV).set_training_precision("bf16x3")
+    with pytest.raises(ValueError):
+        NeRF().to(DEV).set_training_precision("fp16")
+    m, _ = make_model("nerf")
+    x, v = torch.rand(100, 3, device=DEV) * 2 - 1, torch.nn.functional.normalize(torch.randn(100, 3, device=DEV), dim=1)
+    outs = []
+    for prec in ("fp32", "bf16x3", "fp32"):
+        m.set_training_precision(prec)
+        m.zero_grad()
+        c, s = m(x, v)
+        (c.sum() + s.sum()).backward()
+        outs.append((c.detach().clone(), m.block1[0].weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])   # back on the fp32 kernels, bit for bit
+    assert rel(outs[1][0], outs[0][0]) < RTOL
