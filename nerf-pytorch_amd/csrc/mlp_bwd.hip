@@ -832,7 +832,6 @@ extern "C" int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_works
 // narrow ones and the reduction as in nerf_mlp_bwd_weights
 extern "C" int nerf_mlp_bwd_weights_x3(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
                                        int accumulate, void* stream) {
-    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_bwd_weights_x3: the bf16x3 training mode covers the NeRF model only (model %d)", model);
     return bwd_weights_impl(model, M, fwd_workspace, bwd_workspace, grads, accumulate, stream, true);
 }
 
@@ -889,10 +888,15 @@ static int bwd_weights_impl(int model, int64_t M, const float* fwd_workspace, fl
         auto dz = [&](int l) { return bw + (BW_DZ + (size_t)l * H) * Mp; };
         // layer 0: dW0[n][k] = sum_m dz0[m][n] xn[m][k]
         thin(c, dz(0), H, H, ws + WS_X * Mp, 3, W(0), 3, 1, B(0), nullptr);
-        for (int l = 1; l <= 7; ++l) wgrad<256, 256, 2, 4>(c, dz(l), H, h(l - 1), H, W(l), H, H, B(l));
+        for (int l = 1; l <= 7; ++l) {
+            if (x3) wgrad_x3<256, 256>(c, dz(l), H, h(l - 1), H, W(l), H, H, B(l));
+            else wgrad<256, 256, 2, 4>(c, dz(l), H, h(l - 1), H, W(l), H, H, B(l));
+        }
         // feature_remap and the density branch (rank-1 product of dsig) both contract with h7
-        wgrad<256, 256, 2, 4, true>(c, bw + BW_DZF * Mp, H, h(7), H, W(9), H, H, B(9), bw + BW_DSIG * Mp, W(8), B(8));
-        wgrad<128, 256, 2, 4>(c, bw + BW_DZR * Mp, HH, ws + WS_F * Mp, H, W(10), H + DE, H, B(10));
+        if (x3) wgrad_x3<256, 256, true>(c, bw + BW_DZF * Mp, H, h(7), H, W(9), H, H, B(9), bw + BW_DSIG * Mp, W(8), B(8));
+        else wgrad<256, 256, 2, 4, true>(c, bw + BW_DZF * Mp, H, h(7), H, W(9), H, H, B(9), bw + BW_DSIG * Mp, W(8), B(8));
+        if (x3) wgrad_x3<128, 256>(c, bw + BW_DZR * Mp, HH, ws + WS_F * Mp, H, W(10), H + DE, H, B(10));
+        else wgrad<128, 256, 2, 4>(c, bw + BW_DZR * Mp, HH, ws + WS_F * Mp, H, W(10), H + DE, H, B(10));
         wgrad<128, 32, 4, 1>(c, bw + BW_DZR * Mp, HH, ws + WS_DE * Mp, DE_P, W(10) + H, H + DE, DE, nullptr);
         thin(c, ws + WS_G * Mp, HH, HH, bw + BW_DZO * Mp, 3, W(11), 1, HH, nullptr, B(11));
         return reduce_all(c);

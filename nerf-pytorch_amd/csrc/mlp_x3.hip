@@ -715,14 +715,402 @@ __global__ __launch_bounds__(X3_THREADS, 1) void nerf_dgrad_x3_kernel(X3BwdArgs 
     }
 }
 
+
+// =====================================================================================================================
+// Siren (nerf/models.py:185-203) in the same mode: sine layers instead of ReLU layers.  The derivative w0 cos(w0 z) of
+// a sine layer has no bits to hide in: like the fp32 kernels, the forward stores it per layer as a tile in the
+// accumulator order of THESE kernels (piece ni*4 + g/4 of a lane = its registers 4 (g/4) .. + 3 of tile ni, 16 bytes, at
+// float offset (piece * 512 + tid) * 4 of the layer's [64][256] region), which the data-gradient kernel reads back as
+// eight coalesced 16-byte loads per lane.
+// =====================================================================================================================
+namespace x3s {
+using namespace lay;
+constexpr size_t elems(int Kp, int N) { return (size_t)3 * Kp * N; }
+constexpr size_t F_L1 = 0;                                   // L1..L7
+constexpr size_t F_FEAT = F_L1 + 7 * elems(H, H);
+constexpr size_t F_RGBA = F_FEAT + elems(H, H);
+constexpr size_t F_RGBB = F_RGBA + elems(H, HH);
+constexpr size_t D_RGB = F_RGBB + elems(DE_P, HH);
+constexpr size_t D_FEAT = D_RGB + elems(HH, H);
+constexpr size_t D_L7 = D_FEAT + elems(H, H);
+constexpr size_t TOTAL = D_L7 + 7 * elems(H, H);
+constexpr size_t d_img(int layer) { return D_L7 + (size_t)(7 - layer) * elems(H, H); }   // layer 1..7
+static_assert(TOTAL % 8 == 0 && lay::siren::PACKED_FLOATS % 4 == 0, "16-byte pieces");
+constexpr size_t TOTAL_FLOATS = TOTAL / 2;
+}  // namespace x3s
+
+__device__ __forceinline__ float* x3_cos_piece(float* region, int piece, int tid) { return region + ((size_t)piece * X3_THREADS + tid) * 4; }
+
+// Epilogue of a hidden sine layer: h = sin(z) (table form: the arguments of sine layers fed by sines are bounded) as
+// fp32 to the workspace and as three terms to the planes, cos(z) to the layer's derivative tile.
+__device__ __forceinline__ void x3_sine_epilogue(unsigned char* planes, f32x16 (&acc)[2], int ncol0, int wrow0, int lane, int tid,
+                                                 float* __restrict__ gout, float* __restrict__ gcos) {
+    const int r = lane & 31, h = lane >> 5;
+    const int col = ncol0 + 2 * r;
+    const __amdgpu_buffer_rsrc_t g_rsrc = make_rsrc(gout, (unsigned)(TR * lay::H * 4));
+    const int g_voff = ((wrow0 + 4 * h) * lay::H + col) * 4;
+    const __amdgpu_buffer_rsrc_t c_rsrc = make_rsrc(gcos, (unsigned)(TR * lay::H * 4));
+    unsigned char* pl = planes + (wrow0 + 4 * h) * LDPB + col * 2;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        SinCosPair pr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sincos_tab_issue((f32x2){acc[0][4 * q4 + j], acc[1][4 * q4 + j]}, pr[j]);
+        f32x4 c0, c1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row0 = j + 8 * q4;      // (g & 3) + 8 (g >> 2), + wrow0 + 4 h
+            f32x2 sn, cs;
+            sincos_tab_finish(pr[j], sn, cs);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, sn), g_rsrc, g_voff, row0 * lay::H * 4, 2);
+            unsigned w[3];
+            split2(sn[0], sn[1], w);
+            store_terms(pl, row0 * LDPB, w);
+            c0[j] = cs[0];
+            c1[j] = cs[1];
+        }
+        // 16-byte stores with the piece offset in the vector offset and a constant scalar offset (mlp_device.h, sine_epilogue,
+        // explains why wide stores keep their offset out of a scalar register)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, c0), c_rsrc, (q4 * X3_THREADS + tid) * 16, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, c1), c_rsrc, ((4 + q4) * X3_THREADS + tid) * 16, 0, 2);
+    }
+}
+
+// Backward epilogue of a sine layer: dz = (acc [+ dsig[row] * sigw[col]]) * stored derivative
+template <bool RANK1, bool TO_PLANES>
+__device__ __forceinline__ void x3_sine_bwd_epilogue(unsigned char* planes, f32x16 (&acc)[2], int ncol0, int wrow0, int lane,
+                                                     float* __restrict__ gout, const f32x4 (&dv)[8], const float* dsig_lds,
+                                                     const float* __restrict__ sigw) {
+    const int r = lane & 31, h = lane >> 5;
+    const int col = ncol0 + 2 * r;
+    const __amdgpu_buffer_rsrc_t g_rsrc = make_rsrc(gout, (unsigned)(TR * lay::H * 4));
+    const int g_voff = ((wrow0 + 4 * h) * lay::H + col) * 4;
+    unsigned char* pl = planes + (wrow0 + 4 * h) * LDPB + col * 2;
+    f32x2 sw = {0.f, 0.f};
+    if constexpr (RANK1) sw = *reinterpret_cast<const f32x2*>(sigw + col);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int row0 = (g & 3) + 8 * (g >> 2);
+        float v[2] = {acc[0][g], acc[1][g]};
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            if constexpr (RANK1) v[ni] = fmaf(dsig_lds[wrow0 + row0 + 4 * h], sw[ni], v[ni]);
+            v[ni] *= dv[ni * 4 + (g >> 2)][g & 3];
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, (f32x2){v[0], v[1]}), g_rsrc, g_voff, row0 * lay::H * 4, 2);
+        if constexpr (TO_PLANES) {
+            unsigned w[3];
+            split2(v[0], v[1], w);
+            store_terms(pl, row0 * LDPB, w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(X3_THREADS, 1) void siren_fwd_x3_kernel(X3FwdArgs a) {
+    using namespace lay;
+    using namespace lay::siren;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
+    float* tab = reinterpret_cast<float*>(smem_x3);
+    unsigned char* planes = smem_x3 + SINCOS_TAB_FLOATS * 4;
+    float* xin = reinterpret_cast<float*>(planes + PLANES_BYTES);
+    float* sraw_s = xin + X3_XIN_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow0 = (wave >> 2) * 32, wcol = wave & 3;
+    const bool per_sample = tid < 256;
+    const size_t m0 = (size_t)blockIdx.x * TR;
+    const float* __restrict__ pk = a.pk;
+    const __bf16* __restrict__ xi = a.x3;
+    float* ws = a.ws;
+    const size_t Mp = a.Mp;
+    auto wsp = [&](size_t off, int width) -> float* { return ws + off * Mp + m0 * width; };
+    const int smp = (tid & 255) / TPS, q = tid % TPS;
+    constexpr size_t EHH = x3s::elems(H, H);
+
+    if (per_sample) load_sincos_table(tab, tid);
+    x3_load_inputs(a, m0, xin, tid);
+    const int ncol0 = wcol * 64;
+    X3Pre<2> pre;
+    x3_prefetch<2, H / 16, ACC_BIAS>(xi + x3s::F_L1, H, ncol0, lane, pk + BIAS + H, pre);
+    __syncthreads();
+    if (tid < TR) {
+        f32x4 v = {xin[tid * 8], xin[tid * 8 + 1], xin[tid * 8 + 2], 0.0f};
+        *reinterpret_cast<f32x4*>(ws + WS_X * Mp + (m0 + tid) * 4) = v;
+    }
+    // layer 0 (3 -> 256, sin(30 z)) on the vector ALU: thread = (column pair, half of the samples), four samples (one value
+    // pair each: the thread's two columns) in flight at a time.  Table form for |30 z| <= 1e5, decided per thread
+    // from the tile's largest |coordinate| (xin[6]); the library's full-range path otherwise.
+    if (per_sample) {
+        const int c = 2 * (tid & 127), s_lo = (tid >> 7) * 32;
+        const float wa0 = pk[W0 + c * 3], wa1 = pk[W0 + c * 3 + 1], wa2 = pk[W0 + c * 3 + 2], ba = pk[BIAS + c];
+        const float wb0 = pk[W0 + c * 3 + 3], wb1 = pk[W0 + c * 3 + 4], wb2 = pk[W0 + c * 3 + 5], bb = pk[BIAS + c + 1];
+        const float bound = 30.0f * (fmaxf(fabsf(wa0) + fabsf(wa1) + fabsf(wa2), fabsf(wb0) + fabsf(wb1) + fabsf(wb2)) * xin[6]
+                                     + fmaxf(fabsf(ba), fabsf(bb)));
+        const bool fast = bound <= 9.9e4f;
+        float* h0 = wsp(WS_H, H);
+        float* c0 = wsp(WS_C, H);
+        // owner of the derivative piece of rows s .. s+3 (s a multiple of 4), columns c / c + 1, in the accumulator order
+        const int owner_lane = (c & 63) >> 1, owner_wcol = c >> 6;
+#pragma unroll 1
+        for (int s0 = s_lo; s0 < s_lo + 32; s0 += 4) {
+            f32x2 sn[4], cs[4];
+            if (fast) {
+                SinCosPair pr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* x = xin + (s0 + j) * 8;
+                    const float za = mul_rn(30.0f, fmaf(x[2], wa2, fmaf(x[1], wa1, fmaf(x[0], wa0, ba))));
+                    const float zb = mul_rn(30.0f, fmaf(x[2], wb2, fmaf(x[1], wb1, fmaf(x[0], wb0, bb))));
+                    sincos_tab_issue((f32x2){za, zb}, pr[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sincos_tab_finish(pr[j], sn[j], cs[j]);
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < 4; ++j) {
+                    const float* x = xin + (s0 + j) * 8;
+                    const float za = mul_rn(30.0f, fmaf(x[2], wa2, fmaf(x[1], wa1, fmaf(x[0], wa0, ba))));
+                    const float zb = mul_rn(30.0f, fmaf(x[2], wb2, fmaf(x[1], wb1, fmaf(x[0], wb0, bb))));
+                    float s_, c_;
+                    sincosf(za, &s_, &c_);
+                    sn[j][0] = s_; cs[j][0] = c_;
+                    sincosf(zb, &s_, &c_);
+                    sn[j][1] = s_; cs[j][1] = c_;
+                }
+            }
+            f32x4 d0, d1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s = s0 + j;
+                *reinterpret_cast<f32x2*>(h0 + (size_t)s * H + c) = sn[j];
+                unsigned w[3];
+                split2(sn[j][0], sn[j][1], w);
+                store_terms(planes, s * LDPB + c * 2, w);
+                d0[j] = 30.0f * cs[j][0];
+                d1[j] = 30.0f * cs[j][1];
+            }
+            const int owner = ((s0 >> 5) * 4 + owner_wcol) * 64 + 32 * ((s0 >> 2) & 1) + owner_lane;
+            const int q4 = (s0 & 31) >> 3;
+            *reinterpret_cast<f32x4*>(x3_cos_piece(c0, q4, owner)) = d0;
+            *reinterpret_cast<f32x4*>(x3_cos_piece(c0, 4 + q4, owner)) = d1;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll 1
+    for (int l = 1; l <= 7; ++l) {
+        mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3s::F_L1 + (size_t)(l - 1) * EHH, H, ncol0, wrow0, lane, acc, pre);
+        x3_prefetch<2, H / 16, ACC_BIAS>(xi + x3s::F_L1 + (size_t)l * EHH, H, ncol0, lane, pk + BIAS + (l + 1) * H, pre);   // feature_remap after L7
+        __syncthreads();
+        x3_sine_epilogue(planes, acc, ncol0, wrow0, lane, tid, wsp(WS_H + (size_t)l * H, H), wsp(WS_C + (size_t)l * H, H));
+        __syncthreads();
+    }
+    // feature_remap on MFMA; the density branch is a dot product of h7, taken from its fp32 copy in the workspace
+    mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3s::F_FEAT, H, ncol0, wrow0, lane, acc, pre);
+    const int nc = wcol * 32;
+    X3Pre<1> pre1;
+    x3_prefetch<1, H / 16, ACC_BIAS>(xi + x3s::F_RGBA, HH, nc, lane, pk + BIAS_RGB, pre1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (per_sample) {
+        const float* h7 = wsp(WS_H + 7 * (size_t)H, H) + (size_t)smp * H;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = 4 * (TPS * i + q);
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(h7 + k);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + SIGW + k);
+            s += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += pk[BIAS_SIG];
+        if (q == 0) {
+            sraw_s[smp] = s;
+            ws[WS_SRAW * Mp + m0 + smp] = s;
+        }
+    }
+    x3_epilogue<0, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_F, H), nullptr, 0, nullptr, nullptr);
+    __syncthreads();
+    // rgb sine layer: [f | de] -> 128
+    {
+        f32x16 acc1[1];
+        mma_layer_x3<1, H / 16, ACC_BIAS>(planes, xi + x3s::F_RGBA, HH, nc, wrow0, lane, acc1, pre1);
+        x3_prefetch<1, DE_P / 16, ACC_KEEP>(xi + x3s::F_RGBB, HH, nc, lane, nullptr, pre1);
+        __syncthreads();
+        unsigned char* stage_de = planes + 128;
+        float* st = reinterpret_cast<float*>(stage_de + smp * LDPB);
+        const auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+        if (per_sample) {
+            if (uniform(xin[7]) * 8.0f <= 9.9e4f) {
+                EncCache<4> dec;
+                enc_compute<4>(xin + smp * 8 + 3, q, dec);
+                x3_enc_store<4>(planes, st, smp, q, dec);
+            } else {
+                x3_enc_slow<4>(planes, st, smp, q, xin + smp * 8 + 3);
+            }
+        }
+        __syncthreads();
+        x3_copy_stage<DE_P>(stage_de, wsp(WS_DE, DE_P), tid);
+        mma_layer_x3<1, DE_P / 16, ACC_KEEP>(planes, xi + x3s::F_RGBB, HH, nc, wrow0, lane, acc1, pre1);
+        __syncthreads();
+        float* gt = reinterpret_cast<float*>(planes);
+        float* gg = wsp(WS_G, HH);
+        float* gc = wsp(WS_CG, HH);
+        const int col = nc + (lane & 31);
+#pragma unroll
+        for (int g8 = 0; g8 < 16; g8 += 8) {
+            SinCosPair pr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sincos_tab_issue((f32x2){acc1[0][g8 + 2 * j], acc1[0][g8 + 2 * j + 1]}, pr[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x2 sn, cs;
+                sincos_tab_finish(pr[j], sn, cs);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int g = g8 + 2 * j + e;
+                    const int row = wrow0 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+                    gt[row * LDG + col] = sn[e];
+                    gg[(size_t)row * HH + col] = sn[e];
+                    gc[(size_t)row * HH + col] = cs[e];
+                }
+            }
+        }
+        __syncthreads();
+        if (per_sample) {
+            float z[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 4 * (TPS * i + q);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(gt + smp * LDG + k);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + WOUT + c * HH + k);
+                    z[c] += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                z[c] += __shfl_xor(z[c], 1);
+                z[c] += __shfl_xor(z[c], 2);
+            }
+            const size_t m = m0 + smp;
+            if (q == 0 && m < (size_t)a.M) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.colors[m * 3 + c] = sigmoidf_(z[c] + pk[BIAS_OUT + c]);
+                a.density[m] = fmaxf(sraw_s[smp], 0.0f) * 10.0f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(X3_THREADS, 1) void siren_dgrad_x3_kernel(X3BwdArgs a) {
+    using namespace lay;
+    using namespace lay::siren;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
+    unsigned char* planes = smem_x3;
+    float* dsig_s = reinterpret_cast<float*>(planes + PLANES_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow0 = (wave >> 2) * 32, wcol = wave & 3;
+    const size_t m0 = (size_t)blockIdx.x * TR;
+    const size_t Mp = a.Mp;
+    const float* __restrict__ pk = a.pk;
+    const __bf16* __restrict__ xi = a.x3;
+    const float* ws = a.ws;
+    float* bw = a.bw;
+    const int ncol0 = wcol * 64;
+    auto dzp = [&](int l) { return bw + (BW_DZ + (size_t)l * H) * Mp + m0 * H; };
+    // this lane's eight derivative pieces of sine layer l
+    auto load_deriv = [&](int l, f32x4 (&dv)[8]) {
+        const f32x4* region = reinterpret_cast<const f32x4*>(ws + (WS_C + (size_t)l * H) * Mp + m0 * H);
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) dv[pc] = region[pc * X3_THREADS + tid];
+    };
+    X3Pre<2> pre;
+    x3_prefetch<2, HH / 16, ACC_ZERO>(xi + x3s::D_RGB, H, ncol0, lane, nullptr, pre);
+    // gradient of the 128 -> 3 sigmoid head through the rgb sine layer's stored cosine: dzr [64][128] into the planes
+    if (tid < 256) {
+        const int smp = tid / TPS, q = tid % TPS;
+        const size_t m = m0 + smp;
+        float dz[3] = {0.f, 0.f, 0.f};
+        float ds = 0.f;
+        if (m < (size_t)a.M) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float col = a.colors[m * 3 + c];
+                dz[c] = a.dcolors[m * 3 + c] * col * (1.0f - col);
+            }
+            ds = ws[WS_SRAW * Mp + m] > 0.0f ? a.ddensity[m] * 10.0f : 0.0f;
+        }
+        if (q == 0) {
+            f32x4 v = {dz[0], dz[1], dz[2], 0.0f};
+            *reinterpret_cast<f32x4*>(bw + BW_DZO * Mp + m * 4) = v;
+            bw[BW_DSIG * Mp + m] = ds;
+            dsig_s[smp] = ds;
+        }
+        const float* wout = pk + WOUT;
+        const float* gsrc = ws + WS_CG * Mp;
+        float* bw_dzr = bw + BW_DZR * Mp;
+#pragma unroll
+        for (int i = 0; i < 32 / TPS; ++i) {
+            const int k = 4 * (TPS * i + q);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wout + k);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wout + HH + k);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wout + 2 * HH + k);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gsrc + m * HH + k);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (dz[0] * w0[e] + dz[1] * w1[e] + dz[2] * w2[e]) * gv[e];
+            *reinterpret_cast<f32x4*>(bw_dzr + m * HH + k) = v;
+            unsigned wa[3], wb[3];
+            split2(v[0], v[1], wa);
+            split2(v[2], v[3], wb);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<u32x2_t*>(planes + p * PLANE_BYTES + smp * LDPB + k * 2) = u32x2_t{wa[p], wb[p]};
+        }
+    }
+    __syncthreads();
+    f32x16 acc[2];
+    f32x4 dv[8];
+    // rgb sine layer (feature part) -> gradient of feature_remap's output (dzf)
+    mma_layer_x3<2, HH / 16, ACC_ZERO>(planes, xi + x3s::D_RGB, H, ncol0, wrow0, lane, acc, pre);
+    x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3s::D_FEAT, H, ncol0, lane, nullptr, pre);
+    __syncthreads();
+    x3_epilogue<4, true>(planes, acc, ncol0, wrow0, lane, bw + BW_DZF * Mp + m0 * H, nullptr, 0, nullptr, nullptr);
+    __syncthreads();
+    // feature_remap + density branch (rank-1) -> dh7, times cos -> dz7
+    load_deriv(7, dv);
+    mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3s::D_FEAT, H, ncol0, wrow0, lane, acc, pre);
+    x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3s::d_img(7), H, ncol0, lane, nullptr, pre);
+    __syncthreads();
+    x3_sine_bwd_epilogue<true, true>(planes, acc, ncol0, wrow0, lane, dzp(7), dv, dsig_s, pk + SIGW);
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 7; l >= 2; --l) {
+        load_deriv(l - 1, dv);
+        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3s::d_img(l), H, ncol0, wrow0, lane, acc, pre);
+        x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3s::d_img(l - 1), H, ncol0, lane, nullptr, pre);
+        __syncthreads();
+        x3_sine_bwd_epilogue<false, true>(planes, acc, ncol0, wrow0, lane, dzp(l - 1), dv, nullptr, nullptr);
+        __syncthreads();
+    }
+    load_deriv(0, dv);
+    mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3s::d_img(1), H, ncol0, wrow0, lane, acc, pre);
+    x3_sine_bwd_epilogue<false, false>(planes, acc, ncol0, wrow0, lane, dzp(0), dv, nullptr, nullptr);
+}
+
 }  // namespace
 
 extern "C" size_t nerf_mlp_packed_x3_floats(int model) {
-    return model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS + x3::TOTAL_FLOATS : 0;
+    return model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS + x3::TOTAL_FLOATS
+         : model == NERF_MODEL_SIREN ? lay::siren::PACKED_FLOATS + x3s::TOTAL_FLOATS : 0;
 }
 
 extern "C" int nerf_mlp_pack_x3(int model, const float* const* params, float* packed, void* stream) {
-    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_pack_x3: the bf16x3 training mode covers the NeRF model only (model %d)", model);
+    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "nerf_mlp_pack_x3: unknown model %d", model);
     NERF_REQUIRE_PTR(params);
     NERF_REQUIRE_PTR(packed);
     int rc = nerf_mlp_pack(model, params, packed, stream);   // the fp32 image comes first (thin vectors, biases, inference)
@@ -730,21 +1118,32 @@ extern "C" int nerf_mlp_pack_x3(int model, const float* const* params, float* pa
     using namespace lay;
     X3PackArgs a;
     for (int i = 0; i < NERF_NUM_PARAM_TENSORS; ++i) a.src[i] = params[i];
-    a.dst = reinterpret_cast<__bf16*>(packed + lay::nerf::PACKED_FLOATS);
     a.njobs = 0;
-    x3_fwd_job(a, 0, PE, 0, H, PE, x3::F_L0, true, true);
-    for (int l = 1; l <= 4; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3::F_L1 + (size_t)(l - 1) * x3::elems(H, H), true, true);
-    x3_fwd_job(a, 10, H + PE, 0, H, H, x3::F_L5A, true, true);
-    x3_fwd_job(a, 10, H + PE, H, H, PE, x3::F_L5B, true, true);
-    for (int l = 6; l <= 8; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3::F_L6 + (size_t)(l - 6) * x3::elems(H, H), true, true);
-    x3_fwd_job(a, 18, H, 0, H, H, x3::F_L9, false, true);
-    x3_fwd_job(a, 20, H + DE, 0, HH, H, x3::F_L10A, true, false);
-    x3_fwd_job(a, 20, H + DE, H, HH, DE, x3::F_L10B, true, false);
-    x3_bwd_job(a, 20, H + DE, H, HH, x3::D10);
-    x3_bwd_job(a, 18, H, H, H, x3::d_img(9));
-    for (int l = 8; l >= 6; --l) x3_bwd_job(a, 2 * l, H, H, H, x3::d_img(l));
-    x3_bwd_job(a, 10, H + PE, H, H, x3::d_img(5));
-    for (int l = 4; l >= 1; --l) x3_bwd_job(a, 2 * l, H, H, H, x3::d_img(l));
+    if (model == NERF_MODEL_NERF) {
+        a.dst = reinterpret_cast<__bf16*>(packed + lay::nerf::PACKED_FLOATS);
+        x3_fwd_job(a, 0, PE, 0, H, PE, x3::F_L0, true, true);
+        for (int l = 1; l <= 4; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3::F_L1 + (size_t)(l - 1) * x3::elems(H, H), true, true);
+        x3_fwd_job(a, 10, H + PE, 0, H, H, x3::F_L5A, true, true);
+        x3_fwd_job(a, 10, H + PE, H, H, PE, x3::F_L5B, true, true);
+        for (int l = 6; l <= 8; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3::F_L6 + (size_t)(l - 6) * x3::elems(H, H), true, true);
+        x3_fwd_job(a, 18, H, 0, H, H, x3::F_L9, false, true);
+        x3_fwd_job(a, 20, H + DE, 0, HH, H, x3::F_L10A, true, false);
+        x3_fwd_job(a, 20, H + DE, H, HH, DE, x3::F_L10B, true, false);
+        x3_bwd_job(a, 20, H + DE, H, HH, x3::D10);
+        x3_bwd_job(a, 18, H, H, H, x3::d_img(9));
+        for (int l = 8; l >= 6; --l) x3_bwd_job(a, 2 * l, H, H, H, x3::d_img(l));
+        x3_bwd_job(a, 10, H + PE, H, H, x3::d_img(5));
+        for (int l = 4; l >= 1; --l) x3_bwd_job(a, 2 * l, H, H, H, x3::d_img(l));
+    } else {
+        a.dst = reinterpret_cast<__bf16*>(packed + lay::siren::PACKED_FLOATS);
+        for (int l = 1; l <= 7; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3s::F_L1 + (size_t)(l - 1) * x3s::elems(H, H), false, true);
+        x3_fwd_job(a, 18, H, 0, H, H, x3s::F_FEAT, false, true);
+        x3_fwd_job(a, 20, H + DE, 0, HH, H, x3s::F_RGBA, false, false);
+        x3_fwd_job(a, 20, H + DE, H, HH, DE, x3s::F_RGBB, false, false);
+        x3_bwd_job(a, 20, H + DE, H, HH, x3s::D_RGB);
+        x3_bwd_job(a, 18, H, H, H, x3s::D_FEAT);
+        for (int l = 7; l >= 1; --l) x3_bwd_job(a, 2 * l, H, H, H, x3s::d_img(l));
+    }
     pack_x3_kernel<<<dim3(a.njobs, 64), 256, 0, (hipStream_t)stream>>>(a);
     return nerf_check_launch("nerf_mlp_pack_x3");
 }
@@ -752,7 +1151,7 @@ extern "C" int nerf_mlp_pack_x3(int model, const float* const* params, float* pa
 extern "C" int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const float* points, const float* dirs,
                                const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray, double near,
                                double far, float* colors, float* density, float* workspace, void* stream) {
-    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_fwd_x3: the bf16x3 training mode covers the NeRF model only (model %d)", model);
+    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "nerf_mlp_fwd_x3: unknown model %d", model);
     NERF_REQUIRE(M >= 0, "nerf_mlp_fwd_x3: M=%lld < 0", (long long)M);
     if (M == 0) return NERF_OK;
     NERF_REQUIRE_PTR(packed);
@@ -770,17 +1169,23 @@ extern "C" int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const 
     const size_t mp = lay::padded_samples(M);
     const size_t tiles = mp / TR;
     NERF_REQUIRE(tiles < (1ull << 31), "nerf_mlp_fwd_x3: too many samples");
-    X3FwdArgs a{packed, reinterpret_cast<const __bf16*>(packed + lay::nerf::PACKED_FLOATS), M, mp, points, dirs, rays_o, rays_d,
+    const size_t fp32_floats = model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS : lay::siren::PACKED_FLOATS;
+    X3FwdArgs a{packed, reinterpret_cast<const __bf16*>(packed + fp32_floats), M, mp, points, dirs, rays_o, rays_d,
                 t, S, t_per_ray, (float)near, (float)(far - near), colors, density, workspace};
     int rc;
-    if ((rc = nerf_set_lds(nerf_fwd_x3_kernel, X3_FWD_LDS_BYTES))) return rc;
-    nerf_fwd_x3_kernel<<<(unsigned)tiles, X3_THREADS, X3_FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    if (model == NERF_MODEL_NERF) {
+        if ((rc = nerf_set_lds(nerf_fwd_x3_kernel, X3_FWD_LDS_BYTES))) return rc;
+        nerf_fwd_x3_kernel<<<(unsigned)tiles, X3_THREADS, X3_FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    } else {
+        if ((rc = nerf_set_lds(siren_fwd_x3_kernel, X3_FWD_LDS_BYTES))) return rc;
+        siren_fwd_x3_kernel<<<(unsigned)tiles, X3_THREADS, X3_FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    }
     return nerf_check_launch("nerf_mlp_fwd_x3");
 }
 
 extern "C" int nerf_mlp_bwd_data_x3(int model, const float* packed, int64_t M, const float* dcolors, const float* ddensity,
                                     const float* colors, const float* fwd_workspace, float* bwd_workspace, void* stream) {
-    NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_bwd_data_x3: the bf16x3 training mode covers the NeRF model only (model %d)", model);
+    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "nerf_mlp_bwd_data_x3: unknown model %d", model);
     NERF_REQUIRE(M >= 1, "nerf_mlp_bwd_data_x3: M=%lld < 1", (long long)M);
     NERF_REQUIRE_PTR(packed);
     NERF_REQUIRE_PTR(dcolors);
@@ -790,10 +1195,16 @@ extern "C" int nerf_mlp_bwd_data_x3(int model, const float* packed, int64_t M, c
     NERF_REQUIRE_PTR(bwd_workspace);
     const size_t Mp = lay::padded_samples(M);
     NERF_REQUIRE(Mp / TR < (1ull << 31), "nerf_mlp_bwd_data_x3: too many samples");
-    X3BwdArgs a{packed, reinterpret_cast<const __bf16*>(packed + lay::nerf::PACKED_FLOATS), M, Mp, dcolors, ddensity, colors,
+    const size_t fp32_floats = model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS : lay::siren::PACKED_FLOATS;
+    X3BwdArgs a{packed, reinterpret_cast<const __bf16*>(packed + fp32_floats), M, Mp, dcolors, ddensity, colors,
                 fwd_workspace, bwd_workspace};
     int rc;
-    if ((rc = nerf_set_lds(nerf_dgrad_x3_kernel, X3_BWD_LDS_BYTES))) return rc;
-    nerf_dgrad_x3_kernel<<<(unsigned)(Mp / TR), X3_THREADS, X3_BWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    if (model == NERF_MODEL_NERF) {
+        if ((rc = nerf_set_lds(nerf_dgrad_x3_kernel, X3_BWD_LDS_BYTES))) return rc;
+        nerf_dgrad_x3_kernel<<<(unsigned)(Mp / TR), X3_THREADS, X3_BWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    } else {
+        if ((rc = nerf_set_lds(siren_dgrad_x3_kernel, X3_BWD_LDS_BYTES))) return rc;
+        siren_dgrad_x3_kernel<<<(unsigned)(Mp / TR), X3_THREADS, X3_BWD_LDS_BYTES, (hipStream_t)stream>>>(a);
+    }
     return nerf_check_launch("nerf_mlp_bwd_data_x3");
 }

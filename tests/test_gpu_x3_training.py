@@ -10,23 +10,25 @@ from test_gpu_parity import DEV, RTOL, T, make_model, rays, rel
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
 @pytest.mark.parametrize("M", [1, 63, 65, 200, 1000, 4096])
-def test_bf16x3_training_holds_fp32_bar(M):
-    model, params = make_model("nerf")
+def test_bf16x3_training_holds_fp32_bar(tag, M):
+    from test_gpu_parity import oracle_fwd
+    model, params = make_model(tag)
     model.set_training_precision("bf16x3")
-    ref_model, _ = make_model("nerf")
+    ref_model, _ = make_model(tag)
     g = torch.Generator().manual_seed(M)
     pts = torch.rand(M, 3, generator=g) * 2 - 1
     dirs = torch.randn(M, 3, generator=g)
     dirs = dirs / dirs.norm(dim=1, keepdim=True)
     gc, gd = torch.randn(M, 3, generator=g), torch.randn(M, generator=g) * 0.1
     with torch.no_grad():
-        _, _, acts = O.nerf_forward(params, pts, dirs, return_acts=True)
+        _, _, acts = oracle_fwd(tag)(params, pts, dirs, return_acts=True)
     keep = O.relu_kink_distance(acts) > 3e-6
     pts, dirs, gc, gd = pts[keep].contiguous(), dirs[keep].contiguous(), gc[keep].contiguous(), gd[keep].contiguous()
     for p in params.values():
         p.requires_grad_(True)
-    c_ref, d_ref = O.nerf_forward(params, pts, dirs)
+    c_ref, d_ref = oracle_fwd(tag)(params, pts, dirs)
     ((c_ref * gc).sum() + (d_ref * gd).sum()).backward()
     colors, dens = model(pts.to(DEV), dirs.to(DEV))
     ((colors * gc.to(DEV)).sum() + (dens * gd.to(DEV)).sum()).backward()
@@ -42,13 +44,16 @@ def test_bf16x3_training_holds_fp32_bar(M):
     assert worst < RTOL
 
 
-def test_bf16x3_render_step_matches_oracle():
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
+def test_bf16x3_render_step_matches_oracle(tag):
     """One training step's gradients through render_nerf (ray mode: positions generated in the kernel, compositing and
     its backward in between), rays chosen clear of every ReLU kink under the draw; both modes against the oracle."""
     from nerf.rendering import render_nerf
-    m3, params = make_model("nerf")
+    from test_gpu_parity import oracle_fwd
+    fwd = oracle_fwd(tag)
+    m3, params = make_model(tag)
     m3.set_training_precision("bf16x3")
-    m32, _ = make_model("nerf")
+    m32, _ = make_model(tag)
     S = 64
     o, d = rays(320, 5)
     torch.manual_seed(11)
@@ -56,7 +61,7 @@ def test_bf16x3_render_step_matches_oracle():
     t = O.stratified_t(2.0, 6.0, S, u)
     with torch.no_grad():
         pos = O.normalize_positions(O.sample_positions(o, d, t), 2.0, 6.0).reshape(-1, 3)
-        _, _, acts = O.nerf_forward(params, pos, d[:, None, :].expand(-1, S, -1).reshape(-1, 3), return_acts=True)
+        _, _, acts = fwd(params, pos, d[:, None, :].expand(-1, S, -1).reshape(-1, 3), return_acts=True)
     keep = (O.relu_kink_distance(acts).reshape(-1, S) > 3e-6).all(dim=1)
     o, d = o[keep][:256].contiguous(), d[keep][:256].contiguous()
     R = o.shape[0]
@@ -64,7 +69,7 @@ def test_bf16x3_render_step_matches_oracle():
     tgt = torch.rand(R, 3, generator=torch.Generator().manual_seed(6))
     for p in params.values():
         p.requires_grad_(True)
-    rgb_ref = O.render(lambda x, v: O.nerf_forward(params, x, v), o, d, 2.0, 6.0, S, [u])
+    rgb_ref = O.render(lambda x, v: fwd(params, x, v), o, d, 2.0, 6.0, S, [u])
     torch.nn.functional.mse_loss(rgb_ref, tgt).backward()
     for name, m in (("bf16x3", m3), ("fp32", m32)):
         torch.manual_seed(11)
@@ -113,7 +118,7 @@ def test_bf16x3_training_is_reproducible_and_tracks_fp32_over_adam_steps():
             loss = torch.nn.functional.mse_loss(rc, tgt) + torch.nn.functional.mse_loss(rf, tgt)
             loss.backward()
             opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         return flat.flat.clone(), start, losses
 
     p3a, start, l3 = run("bf16x3")
@@ -126,10 +131,10 @@ def test_bf16x3_training_is_reproducible_and_tracks_fp32_over_adam_steps():
     assert float((p3a - p32).norm()) <= 2e-2 * moved
 
 
-def test_bf16x3_mode_is_nerf_only_and_switchable():
-    from nerf.models import NeRF, Siren
+def test_bf16x3_mode_is_switchable():
+    from nerf.models import NeRF
     with pytest.raises(NotImplementedError):
-        Siren().to(DEV).set_training_precision("bf16x3")
+        NeRF(hidden_dim=64).to(DEV).set_training_precision("bf16x3")     # the fused kernels' architecture only
     with pytest.raises(ValueError):
         NeRF().to(DEV).set_training_precision("fp16")
     m, _ = make_model("nerf")
