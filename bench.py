@@ -46,12 +46,14 @@ PROFILES = os.path.join(ROOT, "profiles")
 PMC_KERNEL = {("nerf", "mlp_fwd_train"): ("nerf_fwd_kernel", ("true",)), ("nerf", "mlp_bwd_data"): ("nerf_dgrad_kernel", ()),
               ("nerf", "mlp_fwd_infer"): ("nerf_fwd_kernel", ("false", "false")),
               ("siren", "mlp_fwd_train"): ("siren_fwd_kernel", ("true",)), ("siren", "mlp_bwd_data"): ("siren_dgrad_kernel", ()),
-              ("siren", "mlp_fwd_infer"): ("siren_fwd_kernel", ("false", "false"))}
+              ("siren", "mlp_fwd_infer"): ("siren_fwd_kernel", ("false", "false")),
+              ("nerf", "mlp_fwd_train_x3"): ("nerf_fwd_x3_kernel", ()), ("nerf", "mlp_bwd_data_x3"): ("nerf_dgrad_x3_kernel", ())}
 # HBM bytes per MLP evaluation the kernels move BY DESIGN (csrc/mlp_layout.h): the forward writes its workspace
 # (2857 / 4517 floats per sample) and reads 24 B of ray data per 256 samples; the data gradient writes every layer's
 # dY (2693 / 2437 floats) and reads the head's inputs, the ReLU mask words or the stored cosines.  The packed
 # weights (5 MB) stay in the caches.
 DESIGN_BYTES = {("nerf", "mlp_fwd_train"): 4 * 2857, ("nerf", "mlp_bwd_data"): 4 * (2693 + 128 + 72 + 8),
+                ("nerf", "mlp_fwd_train_x3"): 4 * 2857 + 4 * 256, ("nerf", "mlp_bwd_data_x3"): 4 * (2693 + 128 + 72 + 8),   # (+ h8 read back once)
                 ("siren", "mlp_fwd_train"): 4 * 4517, ("siren", "mlp_bwd_data"): 4 * (2437 + 8 * 256 + 256 + 8)}
 
 
@@ -73,7 +75,8 @@ def pmc_traffic_per_sample(model, kernel, profiles=None):
     want = PMC_KERNEL.get((model, kernel))
     if want is None:
         return None, None
-    infix = "" if model == "nerf" else f"_{model}"
+    # (the opt-in bf16x3 training kernels are profiled on the NeRF network only: files r<N>_pmc_x3_*.csv)
+    infix = "_x3" if kernel.endswith("_x3") else ("" if model == "nerf" else f"_{model}")
     metas = sorted(glob.glob(os.path.join(profiles, "r*_pmc_meta.json")),
                    key=lambda f: int(re.search(r"r(\d+)_pmc_meta", f).group(1)), reverse=True)
     for meta_path in metas:       # newest round that profiled this model
@@ -193,8 +196,8 @@ def main():
                     help="bf16 / bf16x3: the opt-in inference modes on the bf16 matrix pipe (--mode infer, nerf only; bf16x3 = "
                          "three-term split at fp32 accuracy); never the default metric")
     ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16x3"],
-                    help="opt-in (never the default line): forward and data gradient of a training step on the bf16 matrix "
-                         "pipe at fp32 accuracy (three bf16 terms per operand); the weight gradient stays on fp32 MFMA; NeRF only")
+                    help="opt-in (never the default line): a training step's forward, data gradient and wide weight-gradient "
+                         "products on the bf16 matrix pipe at fp32 accuracy (three bf16 terms per operand); both networks")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the multi-rank code path on a box with a single GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")

@@ -21,12 +21,14 @@ stats() {   # name, bench arguments...
         > "$OUT/${TAG}_bench_${name}_profiled.json" 2> "$OUT/kt_$name.log" || return 1
     cp "$(find "$OUT/kt_$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_${name}_kernel_stats.csv"
 }
-pmc() {     # name, counters...   (NeRF single-pass workload; name "siren_*" profiles the Siren network instead)
+pmc() {     # name, counters...   (NeRF single-pass workload; name "siren_*" profiles the Siren network instead,
+            #                      name "x3_*" the opt-in bf16x3 training kernels of the NeRF network)
     local name=$1; shift
     local model=nerf
-    case "$name" in siren_*) model=siren;; esac
+    local tp=fp32
+    case "$name" in siren_*) model=siren;; x3_*) tp=bf16x3;; esac
     rm -rf "$OUT/pmc_$name"
-    timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$OUT/pmc_$name" -o p --output-format csv -- python3 bench.py --sampling single --model $model --steps 3 --warmup 1 --no-cpu-baseline \
+    timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$OUT/pmc_$name" -o p --output-format csv -- python3 bench.py --sampling single --model $model --train-precision $tp --steps 3 --warmup 1 --no-cpu-baseline \
         > /dev/null 2> "$OUT/pmc_$name.log" || return 1
     python3 profiles/summarize_pmc.py "$OUT/pmc_$name" > "$OUT/${TAG}_pmc_$name.csv"
 }
@@ -39,11 +41,16 @@ pmc_all() {
     pmc siren_write WRITE_SIZE &&
     pmc siren_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
     pmc siren_insts SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE &&
-    echo '{"samples_per_dispatch": 1048576, "command": "rocprofv3 --pmc <counters> -- python3 bench.py --sampling single [--model siren] --steps 3 --warmup 1 --no-cpu-baseline", "unit": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (profiles/summarize_pmc.py means); files named *_pmc_siren_* are the Siren network"}' > "$OUT/${TAG}_pmc_meta.json"
+    pmc x3_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
+    pmc x3_insts SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE &&
+    pmc x3_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE &&
+    pmc x3_fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
+    pmc x3_write WRITE_SIZE &&
+    echo '{"samples_per_dispatch": 1048576, "command": "rocprofv3 --pmc <counters> -- python3 bench.py --sampling single [--model siren] --steps 3 --warmup 1 --no-cpu-baseline", "unit": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (profiles/summarize_pmc.py means); files named *_pmc_siren_* are the Siren network, *_pmc_x3_* the opt-in bf16x3 training kernels (--train-precision bf16x3)"}' > "$OUT/${TAG}_pmc_meta.json"
 }
 modes() {
     : > "$OUT/${TAG}_bench_modes.jsonl"
-    for args in "--sampling single" "--sampling single --model siren" "--model siren" "--mode infer" "--mode infer --sampling single" \
+    for args in "--sampling single" "--sampling single --model siren" "--model siren" "--train-precision bf16x3" "--train-precision bf16x3 --sampling single" "--train-precision bf16x3 --model siren" "--train-precision bf16x3 --model siren --sampling single" "--train-precision bf16x3 --rays 16384" "--mode infer" "--mode infer --sampling single" \
                 "--mode infer --precision bf16" "--mode infer --precision bf16 --rays 32768" "--mode infer --precision bf16x3" "--mode infer --precision bf16x3 --rays 32768" "--mode infer --model siren" "--mode infer --model siren --precision bf16x3" "--mode infer --precision bf16x3 --rays 640000 --steps 3 --warmup 1" "--mode infer --rays 640000 --steps 3 --warmup 1" \
                 "--rays 1024" "--rays 16384"; do
         timeout -k 10 300 python3 bench.py $args --no-cpu-baseline >> "$OUT/${TAG}_bench_modes.jsonl" 2>> "$OUT/modes.err" || return 1
@@ -61,6 +68,8 @@ fi
 stats hier &&    # the default bench command itself (10 timed steps after 3 warm-ups)
 stats single --steps 6 --warmup 2 --sampling single &&
 stats siren --steps 6 --warmup 2 --sampling single --model siren &&
+stats x3 --steps 6 --warmup 2 --train-precision bf16x3 &&
+stats x3_single --steps 6 --warmup 2 --sampling single --train-precision bf16x3 &&
 stats infer_bf16x3 --steps 6 --warmup 2 --mode infer --precision bf16x3 --rays 32768 &&
 pmc_all &&
 modes &&
