@@ -178,7 +178,7 @@ int nerf_mlp_bwd_data(int model, const float* packed, int64_t M, const float* dc
 int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_workspace, float* bwd_workspace, float* grads,
                          int accumulate, void* stream);
 
-/* ---- opt-in three-term TRAINING mode "bf16x3" (NERF_MODEL_NERF; no counterpart in the reference, whose
+/* ---- opt-in three-term TRAINING mode "bf16x3" (both models; no counterpart in the reference, whose
  * train step, train.py:166-183, is fp32 throughout) ------------------------------------------------------
  * nerf_mlp_fwd with a workspace, and nerf_mlp_bwd_data, on the bf16 matrix pipe with the arithmetic of the bf16x3
  * inference mode above (three bf16 terms per fp32 operand, six exact term products per product, fp32

@@ -1,7 +1,8 @@
-// Opt-in TRAINING kernels of the NeRF MLP (nerf/models.py:62-75 and what autograd derives for it, train.py:181) on the
+// Opt-in TRAINING kernels of the NeRF MLP (nerf/models.py:62-75) and, further down, the Siren MLP (:185-203), with what
+// autograd derives for them (train.py:181), on the
 // bf16 matrix pipe at fp32 accuracy ("bf16x3"): forward with the activation workspace, and the data-gradient chain.
-// The default training path stays the fp32 MFMA kernels of mlp_fwd.hip / mlp_bwd.hip; the weight-gradient GEMMs
-// (nerf_mlp_bwd_weights) are shared by both and stay on fp32 MFMA.
+// The default training path stays the fp32 MFMA kernels of mlp_fwd.hip / mlp_bwd.hip; the weight-gradient GEMMs read
+// the same workspaces (nerf_mlp_bwd_weights on fp32 MFMA, or nerf_mlp_bwd_weights_x3 with this file's arithmetic).
 //
 // Arithmetic (the three-term expansion of mlp_bf16.hip): every fp32 operand is the exact sum of three bf16 terms,
 // x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); a product of two operands is formed from

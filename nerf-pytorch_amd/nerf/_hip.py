@@ -278,7 +278,7 @@ def mlp_pack_x3(model: int, params: Sequence[torch.Tensor], out: Optional[torch.
         raise ValueError(f"expected {NUM_PARAM_TENSORS} parameter tensors, got {len(params)}")
     n = lib.nerf_mlp_packed_x3_floats(model)
     if n == 0:
-        raise NotImplementedError("the bf16x3 training mode covers the NeRF model only")
+        raise NotImplementedError("this model has no bf16x3 training kernels")
     if out is None or out.numel() != n:
         out = torch.empty(n, dtype=torch.float32, device=params[0].device)
     ptrs = (c_void_p * NUM_PARAM_TENSORS)(*[_dev(p, f"params[{i}]") for i, p in enumerate(params)])

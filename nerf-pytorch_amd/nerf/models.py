@@ -49,15 +49,15 @@ class _FusedMLP(nn.Module):
         """'fp32' (default: the fp32 MFMA kernels, the path every headline figure is measured on) or the opt-in 'bf16x3':
         forward and data-gradient chain on the bf16 matrix pipe with every fp32 operand split into three bf16 terms and
         every product formed from six term products accumulated in fp32 -- fp32 accuracy (the mode holds the fp32
-        path's 1e-5 bar, gradients included) at a fraction of the matrix-pipe time; the weight-gradient products
-        stay on the fp32 MFMA kernels.  NeRF only.  Passes without gradients are not affected (see
-        set_inference_precision)."""
+        path's 1e-5 bar, gradients included) at a fraction of the matrix-pipe time; so do the wide weight-gradient
+        products (the narrow ones stay on fp32 MFMA).  Both models, default architecture.  Passes without gradients are
+        not affected (see set_inference_precision)."""
         if precision not in ("fp32", "bf16x3"):
             raise ValueError("training precision must be 'fp32' or 'bf16x3'")
         if precision == "bf16x3":
             self._check_supported()
             if _hip.lib.nerf_mlp_packed_x3_floats(self.model_id) == 0:
-                raise NotImplementedError("the bf16x3 training mode covers the NeRF model only")
+                raise NotImplementedError("this model has no bf16x3 training kernels")
         if precision != self.training_precision:
             self._packed = PackedWeights(self.model_id, _hip.mlp_pack_x3 if precision == "bf16x3" else _hip.mlp_pack)
         self.training_precision = precision

@@ -8,7 +8,7 @@ torch.optim.Adam + LambdaLR exactly as the reference), TensorBoard is optional, 
 Extension (no counterpart in the reference): the config key `num_fine_samples = N` (N > 0) trains a
 coarse and a fine network with inverse-CDF re-sampling (`num_samples` coarse + N fine samples per
 ray, both losses); checkpoints then hold both networks under `coarse.` / `fine.` key prefixes.
-Extension: the config key `train_precision = bf16x3` (NeRF only; default fp32) runs the training kernels on the bf16
+Extension: the config key `train_precision = bf16x3` (default fp32) runs the training kernels on the bf16
 matrix pipe at fp32 accuracy (three bf16 terms per operand; nerf/models.py set_training_precision).
 """
 import argparse
@@ -105,7 +105,7 @@ def main(argv=None):
     train_precision = cfg.get('train_precision', 'fp32').lower()
     if train_precision != 'fp32':
         for net in nets:
-            net.set_training_precision(train_precision)   # raises for anything but 'bf16x3' on a NeRF
+            net.set_training_precision(train_precision)   # raises for anything but 'fp32' / 'bf16x3'
 
     def render(o, d, us=None, ufs=None):
         """rgb predictions of every network that is trained ([single] or [coarse, fine])."""

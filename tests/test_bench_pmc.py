@@ -46,7 +46,9 @@ def test_committed_passes_give_traffic_close_to_design(entry):
         pytest.skip(f"no committed counter pass for {model}{infix}")
     assert per_sample is not None, f"{entry}: counter files {have} exist but no row matched"
     assert all(os.path.exists(os.path.join(ROOT, f)) for f in files)
-    tol = 0.10 if kernel.startswith("mlp_fwd_train") else 0.25
+    # (the bf16x3 kernels stream a weight image three times the fp32 one's size per 64-sample tile: its re-fetches past the
+    # eight L2s, 3.1 GB per 1,048,576-sample forward, come on top of the by-design workspace bytes)
+    tol = 0.10 if kernel == "mlp_fwd_train" else 0.25
     want = bench.DESIGN_BYTES[entry]
     assert abs(per_sample - want) <= tol * want, (entry, per_sample, want)
 
