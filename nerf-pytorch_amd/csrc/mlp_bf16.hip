@@ -728,24 +728,11 @@ extern "C" void nerf_diag_bf16_stamps(unsigned long long* device_buffer) { g_bf1
 #endif
 
 extern "C" size_t nerf_mlp_packed_bf16_bytes(int model) { return model == NERF_MODEL_NERF ? Geo<1, NERF_MODEL_NERF>::PACKED_BYTES : 0; }
-extern "C" size_t nerf_mlp_packed_bf16x3_bytes(int model) {
-    return model == NERF_MODEL_NERF ? Geo<3, NERF_MODEL_NERF>::PACKED_BYTES
-         : model == NERF_MODEL_SIREN ? Geo<3, NERF_MODEL_SIREN>::PACKED_BYTES : 0;
-}
-
 extern "C" int nerf_mlp_pack_bf16(int model, const float* const* params, void* packed, void* stream) {
     NERF_REQUIRE(model == NERF_MODEL_NERF, "nerf_mlp_pack_bf16: the bf16 mode covers the NeRF model only (model %d)", model);
     NERF_REQUIRE_PTR(params);
     NERF_REQUIRE_PTR(packed);
     return pack_image<1, NERF_MODEL_NERF>(params, packed, stream, "nerf_mlp_pack_bf16");
-}
-
-extern "C" int nerf_mlp_pack_bf16x3(int model, const float* const* params, void* packed, void* stream) {
-    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "nerf_mlp_pack_bf16x3: unknown model %d", model);
-    NERF_REQUIRE_PTR(params);
-    NERF_REQUIRE_PTR(packed);
-    return model == NERF_MODEL_NERF ? pack_image<3, NERF_MODEL_NERF>(params, packed, stream, "nerf_mlp_pack_bf16x3")
-                                    : pack_image<3, NERF_MODEL_SIREN>(params, packed, stream, "nerf_mlp_pack_bf16x3");
 }
 
 extern "C" int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const float* points, const float* dirs,
@@ -755,9 +742,3 @@ extern "C" int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const
                         density, stream);
 }
 
-extern "C" int nerf_mlp_fwd_bf16x3(int model, const void* packed, int64_t M, const float* points, const float* dirs,
-                                   const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray,
-                                   double near, double far, float* colors, float* density, void* stream) {
-    return fwd_terms<3>("nerf_mlp_fwd_bf16x3", model, packed, M, points, dirs, rays_o, rays_d, t, S, t_per_ray, near, far, colors,
-                        density, stream);
-}

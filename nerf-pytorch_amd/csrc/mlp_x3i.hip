@@ -1,0 +1,585 @@
+// Three-term ("bf16x3") inference forward on 16-sample tiles: v_mfma_f32_16x16x32_bf16, two waves per SIMD.
+//
+// Arithmetic: every fp32 operand is the exact sum of three bf16 terms, x = x0 + x1 + x2 with x0 = bf16(x),
+// x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (the subtractions are exact), and a product is formed from the six term
+// products that reach fp32 precision,
+//     w*x ~= w0*x0 + w0*x1 + w0*x2 + w1*x0 + w1*x1 + w2*x0      (what is dropped is below 2^-24 of |w*x|),
+// each exact in the MFMA's fp32 accumulator: the results carry the rounding of an fp32 accumulation and nothing else
+// (nerf/models.py:62-75, :185-203 at the fp32 parity bar).
+//
+// Orientation (as in mlp_bf16.hip): a layer is computed transposed, D[out feature][sample] = sum_k W[out][k] X[k][sample],
+// weights = A operand (streamed through an LDS ring, one 1 KiB unit = one fragment of 16 rows x 32 k; the three terms of
+// a fragment are three consecutive units), activations = B operand, chained from layer to layer in registers.  Operand
+// maps of the 16x16x32 MFMA, lane l = (c = l & 15, q = l >> 4):
+//   A: row c, k = 8q .. 8q+7        B: column (sample) c, k = 8q .. 8q+7        D register g: row 4q + g, column c.
+// Two 16-feature output tiles (2s, 2s+1) of a layer give the B fragment of the next layer's k-step s: element j of lane
+// (c, q) is feature 32s + 4q + j for j < 4 and 32s + 16 + 4q + (j - 4) for j >= 4, and the weight image stores its
+// fragments in that k order.
+//
+// Why this shape.  On 32-sample tiles (the kernel this one replaced) a wave holds 192 registers of activation terms + 144
+// of accumulators: one wave per SIMD, and nothing runs on the matrix pipe while that wave splits its outputs into
+// terms (11 vector instructions per value pair) or issues its LDS-DMA pieces.  Here a wave owns 16 samples (96 + 68
+// registers) and two waves share a SIMD.  Every 1 KiB unit then feeds 16 instead of 32 samples per read: 128 bytes of
+// LDS reads per cycle and CU at the full MFMA rate, half of what ds_read_b128 delivers.  The chip also holds a higher
+// clock under this MFMA shape than under 32x32x16.
+//
+// Ring protocol.  The image is streamed once per workgroup through NBUF buffers of one chunk (24 units: every layer of
+// both models but the last is a whole number of them) each; every thread moves its own 16-byte pieces of every chunk
+// (buffer_load ... lds, no staging registers).  Four units into chunk c every wave waits for its pieces of chunk c+1
+// (counted vmcnt: chunk c+2 may stay in flight), all waves meet at one barrier -- which publishes chunk c+1 and, each
+// wave having read at least one unit of chunk c, frees the buffer of chunk c-1 -- and chunk c+3 is requested into that
+// buffer, one piece per following unit.  The fragment reads in flight at the barrier are untouched by it.
+//
+// Measured and not kept (all with results bit for bit unchanged): waves 4-7 trailing waves 0-3 by one or two chunks so
+// that the splitting epilogues of the two waves of a SIMD do not coincide (a barrier per chunk keeps the wave groups
+// within one chunk of each other whatever the lag: 3 % slower); the split of finished tiles placed between the MFMAs of
+// the layer's last k-step (same cycles: there the 13 vector instructions per value pair are 4-5 per MFMA, and only 2
+// per MFMA issue in its shadow -- tests/micro/coexec16.hip); LDS-DMA pieces of the two waves of a SIMD at different
+// units; request distance 4 and 5 chunks; 8 fragment reads in flight.  Where the cycles go (counters, 1,048,576
+// samples): the matrix pipe is busy 0.76 of them; the rest is the LDS-DMA instructions (3 per thread and chunk, some
+// 40-60 cycles of issue each: 12 %) and the splitting epilogues (9 %).
+#include "bf16_common.h"
+
+using namespace bf16k;
+
+namespace {
+
+constexpr int NBUF = 4;
+constexpr int AHEAD = 3;             // a chunk is requested three chunks before it is read
+
+constexpr int WAVES = 8;
+constexpr int WG_THREADS = 64 * WAVES;
+constexpr int WG_SAMPLES = 16 * WAVES;
+constexpr int CHUNK_UNITS = 24;
+constexpr int CHUNK_BYTES = CHUNK_UNITS * UNIT_BYTES;
+constexpr int PER_CHUNK = CHUNK_BYTES / (16 * WG_THREADS);   // LDS-DMA instructions per thread and chunk
+static_assert(PER_CHUNK * 16 * WG_THREADS == CHUNK_BYTES, "whole pieces");
+
+constexpr int enc_ks32(int enc) { return enc == ENC_PE ? 2 : (enc == ENC_DE || enc == ENC_XYZ) ? 1 : 0; }
+
+template <int MODEL>
+struct Geo {
+    using N = Net<MODEL>;
+    static constexpr int NL = N::NL;
+    static constexpr int n_ot(int l) { return (N::LAYERS[l].n_out + 15) / 16; }
+    static constexpr int nks_acc(int l) { return N::LAYERS[l].nks_acc / 2; }
+    static constexpr int nks(int l) { return nks_acc(l) + enc_ks32(N::LAYERS[l].enc); }
+    static constexpr int layer_units(int l) { return 3 * n_ot(l) * nks(l); }
+    static constexpr int layer_chunks(int l) { return (layer_units(l) + CHUNK_UNITS - 1) / CHUNK_UNITS; }
+    static constexpr int chunk0(int l) {
+        int c = 0;
+        for (int i = 0; i < l; ++i) c += layer_chunks(i);
+        return c;
+    }
+    static constexpr int bias_tile0(int l) {
+        int t = 0;
+        for (int i = 0; i < l; ++i) t += n_ot(i);
+        return t;
+    }
+    static constexpr int NCHUNK = chunk0(NL);
+    static constexpr int NBIAS_TILES = bias_tile0(NL);
+    static constexpr size_t BIAS_FLOATS = (size_t)NBIAS_TILES * 16;
+    static constexpr size_t IMG_BYTES = (size_t)NCHUNK * CHUNK_BYTES;
+    static constexpr size_t PACKED_BYTES = IMG_BYTES + BIAS_FLOATS * 4;
+};
+constexpr int NBIAS_TILES_MAX = 170;                       // LDS room for the bias image of either model
+static_assert(Geo<NERF_MODEL_NERF>::NBIAS_TILES == 170 && Geo<NERF_MODEL_SIREN>::NBIAS_TILES <= NBIAS_TILES_MAX, "bias image");
+constexpr int LDS_BYTES = NBUF * CHUNK_BYTES + NBIAS_TILES_MAX * 16 * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
+
+// Input column of weight element (k-step ks, lane group q, fragment element j) of layer L, or -1.
+// Encoding slots: every lane group owns the same NUMBER of frequencies, so that all lanes run the same code:
+//   position encoding (nerf/encoding.py:14-18, 10 frequencies; 2 k-steps = 16 slots per group): slots 0..11 the frequencies
+//     2q and 2q+1 (sin xyz, cos xyz each), slots 12..14 sin (q even) or cos (q odd) of frequency 8 + q/2, slot 15 the raw
+//     coordinate q (none for q = 3);
+//   direction encoding (4 frequencies; 1 k-step = 8 slots per group): slots 0..5 frequency q, slot 6 the raw component q;
+//   raw coordinates of the Siren model: slots 0..2 of group 0.
+__host__ __device__ inline int k_column16(const LayerInfo& L, int ks, int q, int j) {
+    const int nka = L.nks_acc / 2;
+    if (ks < nka) {
+        const int f = 32 * ks + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
+        return f < L.n_in ? f : -1;
+    }
+    const int e = 8 * (ks - nka) + j;
+    if (L.enc == ENC_XYZ) return (q == 0 && e < 3) ? L.n_in + e : -1;
+    if (L.enc == ENC_PE) {
+        if (e < 12) return L.n_in + 3 + 6 * (2 * q + e / 6) + e % 6;
+        if (e < 15) return L.n_in + 3 + 6 * (8 + (q >> 1)) + 3 * (q & 1) + (e - 12);
+        return q < 3 ? L.n_in + q : -1;
+    }
+    if (e < 6) return L.n_in + 3 + 6 * q + e;
+    if (e == 6) return q < 3 ? L.n_in + q : -1;
+    return -1;
+}
+
+struct PackArgs {
+    const float* src[NERF_NUM_PARAM_TENSORS];
+    unsigned char* dst;
+    LayerInfo layers[NL_MAX];
+    int chunk0[NL_MAX + 1];
+    int bias_tile0[NL_MAX + 1];
+};
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void pack_x3i_kernel(PackArgs a) {
+    using G = Geo<MODEL>;
+    const int p = blockIdx.x * 256 + threadIdx.x;  // one 16-byte piece: unit, lane
+    if (p < G::NCHUNK * CHUNK_UNITS * 64) {
+        const int chunk = p / (CHUNK_UNITS * 64), unit = (p / 64) % CHUNK_UNITS, lane = p & 63;
+        int l = 0;
+        while (chunk >= a.chunk0[l + 1]) ++l;
+        const LayerInfo L = a.layers[l];
+        const int n_ot = (L.n_out + 15) / 16, nks = L.nks_acc / 2 + enc_ks32(L.enc);
+        const int up = (chunk - a.chunk0[l]) * CHUNK_UNITS + unit;
+        const int plane = up % 3, u = up / 3;       // the three terms of a fragment are consecutive units
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.0f;
+        if (u < n_ot * nks) {
+            const int ks = u / n_ot, ot = u % n_ot;
+            const int out = 16 * ot + (lane & 15), q = lane >> 4;
+            if (out < L.n_out) {
+                const float* __restrict__ w = (L.last_row_tensor >= 0 && out == L.n_out - 1)
+                                                  ? a.src[L.last_row_tensor] : a.src[L.wtensor] + (size_t)out * L.ld;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int col = k_column16(L, ks, q, j);
+                    if (col >= 0) v[j] = bf16_term(w[col], plane);
+                }
+            }
+        }
+        *reinterpret_cast<bf16x8*>(a.dst + (size_t)p * 16) = v;
+    }
+    // bias image: 16 floats per output tile
+    if (p < G::NBIAS_TILES * 16) {
+        const int tile = p >> 4, e = p & 15;
+        int l = 0;
+        while (tile >= a.bias_tile0[l + 1]) ++l;
+        const LayerInfo L = a.layers[l];
+        const int out = 16 * (tile - a.bias_tile0[l]) + e;
+        float b = 0.0f;
+        if (out < L.n_out) b = (L.last_row_tensor >= 0 && out == L.n_out - 1) ? a.src[L.last_row_tensor + 1][0] : a.src[L.wtensor + 1][out];
+        reinterpret_cast<float*>(a.dst + G::IMG_BYTES)[p] = b;
+    }
+}
+
+// ---- forward -----------------------------------------------------------------------------
+struct FwdArgs {
+    const unsigned char* img;
+    int64_t M;
+    const float* points;
+    const float* dirs;
+    const float* rays_o;
+    const float* rays_d;
+    const float* t;
+    int S;
+    int t_per_ray;
+    float nearf, spanf;
+    float* colors;
+    float* density;
+};
+
+struct Ring {
+    const unsigned char* img;
+    unsigned char* lds;
+    int next;        // chunk the next buffer switch hands out
+    unsigned voff;   // this thread's byte offset inside a slice of a chunk (16 * tid)
+    int wave;
+    int nchunk, img_bytes;
+};
+
+// piece i (16 bytes per thread) of a chunk: global memory -> LDS without staging registers (buffer form of the LDS-DMA:
+// image base and size in a scalar resource, chunk and slice in the scalar offset, 16 * tid in the one vector offset)
+__device__ __forceinline__ void ring_issue_piece(const Ring& r, int chunk, int i) {
+    if (chunk < r.nchunk) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(r.img), 0, r.img_bytes, 0x00020000);
+        unsigned char* dst = r.lds + (chunk & (NBUF - 1)) * CHUNK_BYTES + 16 * 64 * r.wave;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + i * 16 * WG_THREADS), 16,
+                                                 (int)r.voff, chunk * CHUNK_BYTES + i * 16 * WG_THREADS, 0, 0);
+    }
+}
+__device__ __forceinline__ void ring_issue(const Ring& r, int chunk) {
+#pragma unroll
+    for (int i = 0; i < PER_CHUNK; ++i) ring_issue_piece(r, chunk, i);
+}
+
+// publication of the next chunk (header comment).  REM = chunks of the stream that follow the one being read (2 = two
+// or more): with fewer than two, no younger request exists that could stay in flight.
+template <int REM>
+__device__ __forceinline__ void ring_publish_next() {
+    if constexpr (REM >= 1) {
+        if constexpr (REM >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+constexpr int NOT_MAX = 17;
+
+// The 3, 2 or 1 MFMAs of a unit (term p of the weights meets terms 0 .. 2-p of the activations), accumulating IN PLACE.
+// Through the builtin the compiler treats the result as a new value and, accumulator tiles and A fragments both being
+// four registers wide, rotates them through each other: results land in the registers of the fragment just consumed
+// and the next fragment is loaded over the old accumulator, every such load behind a software wait of 5-7 cycles for the
+// MFMA's read of its C operand -- and with two waves per SIMD (the partner's MFMAs delay this wave's) those waits were
+// not long enough: wrong sums.  The asm form pins destination = C operand; what the compiler no longer sees is the
+// MFMA's result latency, which settle() covers.
+template <int N>
+__device__ __forceinline__ void mfma16_unit(f32x4& acc, const u32x4& a, const u32x4& b0, const u32x4& b1, const u32x4& b2) {
+    if constexpr (N == 3)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %4, %0"
+                     : "+v"(acc) : "v"(a), "v"(b0), "v"(b1), "v"(b2));
+    else if constexpr (N == 2)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %3, %0" : "+v"(acc) : "v"(a), "v"(b0), "v"(b1));
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b0));
+}
+// Wait states between the last MFMAs of a layer and the first vector instruction that reads their accumulators (once
+// per layer; the hardware does not interlock this).  The tiles are operands so that the compiler cannot move a read of
+// them in front of the wait; tiles finished earlier in the layer are dozens of MFMAs old.
+__device__ __forceinline__ void settle(f32x4& last, f32x4& before_last) {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(last), "+v"(before_last));
+}
+__device__ __forceinline__ void settle(f32x4& last) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(last)); }
+
+template <int NOT>
+__device__ __forceinline__ void init_bias(f32x4 (&acc)[NOT_MAX], const float* bias_lds, int tile0, int q) {
+    const float* base = bias_lds + tile0 * 16 + q * 4;
+#pragma unroll
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = *reinterpret_cast<const f32x4*>(base + ot * 16);
+}
+
+// acc[ot] += W tile (ot, ks) * B(ks) for all ks, consuming the layer's units in image order; k-steps below NKS_A take
+// their B fragment from X, the rest from XE (an encoding).  A fragments are read from LDS PF units ahead of the MFMAs
+// that use them.  Unit 3g+p is term p of fragment g.
+// TAIL = chunks that follow this layer's last chunk in the stream the kernel reads (2 = two or more).
+// FIRST_OT: output tiles below it are not computed (their units still pass through the ring).
+template <int NOT, int NKS_A, int NKS_E, int TAIL, int FIRST_OT = 0>
+__device__ __forceinline__ void mma_layer(Ring& r, int lane, f32x4 (&acc)[NOT_MAX], const u32x4 (&X)[3][8], const u32x4 (&XE)[3][2]) {
+    constexpr int CU = CHUNK_UNITS;
+    constexpr int NKS = NKS_A + NKS_E, UNITS = 3 * NOT * NKS, CHUNKS = (UNITS + CU - 1) / CU;
+    constexpr int PF = 4;            // fragment reads in flight
+    constexpr int PUBLISH_AT = PF;   // unit of a chunk at whose fetch the next chunk is published
+    static_assert(UNITS >= PF && (UNITS % CU == 0 || UNITS % CU >= PUBLISH_AT + PER_CHUNK), "chunk too short");
+    static_assert(PUBLISH_AT + PER_CHUNK <= CU, "pieces of a chunk are requested inside one chunk");
+    const unsigned char* buf = nullptr;
+    u32x4 a[PF];
+    auto fetch = [&](auto U) {
+        constexpr int u = decltype(U)::value;
+        if constexpr (u % CU == 0) {
+            // one address register per chunk (its offset hidden from the compiler), the units at immediate offsets
+            unsigned off = (unsigned)(r.next & (NBUF - 1)) * CHUNK_BYTES + 16u * (unsigned)lane;
+            asm volatile("" : "+v"(off));
+            ++r.next;
+            buf = r.lds + off;
+        }
+        constexpr int rem = (CHUNKS - 1 - u / CU) + TAIL;
+        if constexpr (u % CU == PUBLISH_AT) ring_publish_next<(rem >= 2 ? 2 : rem)>();
+        if constexpr (rem >= 1 && u % CU >= PUBLISH_AT && u % CU < PUBLISH_AT + PER_CHUNK)
+            ring_issue_piece(r, r.next - 1 + AHEAD, u % CU - PUBLISH_AT);   // r.next - 1 is the chunk being read
+        a[u % PF] = *reinterpret_cast<const u32x4*>(buf + (u % CU) * UNIT_BYTES);
+    };
+    static_for<PF>(fetch);
+    static_for<UNITS>([&](auto U) {
+        constexpr int u = decltype(U)::value, p = u % 3, ks = (u / 3) / NOT, ot = (u / 3) % NOT;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ot >= FIRST_OT) {
+            if constexpr (ks < NKS_A) mfma16_unit<3 - p>(acc[ot], a[u % PF], X[0][ks], X[1][ks], X[2][ks]);
+            else mfma16_unit<3 - p>(acc[ot], a[u % PF], XE[0][ks - NKS_A], XE[1][ks - NKS_A], XE[2][ks - NKS_A]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (u + PF < UNITS) fetch(std::integral_constant<int, u + PF>{});
+    });
+    if constexpr (NOT >= 2) settle(acc[NOT - 1], acc[NOT - 2]);
+    else settle(acc[0]);
+}
+
+// accumulator tiles -> B fragments of the next layer (one k-step per PAIR of 16-feature tiles), through the layer's
+// activation: FR_SIN is sin(z) of a hidden sine layer (nerf/models.py:89-90 with w0 = 1), FR_SIN30 the first sine layer's sin(30 z)
+enum FragAct { FR_NONE = 0, FR_RELU = 1, FR_SIN = 2, FR_SIN30 = 3 };
+template <int NPAIR, int ACT>
+__device__ __forceinline__ void to_frags(const f32x4 (&acc)[NOT_MAX], u32x4 (&X)[3][8]) {
+#pragma unroll
+    for (int s = 0; s < NPAIR; ++s)
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            float v0 = acc[2 * s + (jp >> 1)][2 * (jp & 1)], v1 = acc[2 * s + (jp >> 1)][2 * (jp & 1) + 1];
+            if constexpr (ACT == FR_RELU) {   // (fmaxf puts a canonicalising v_max v, v, v in front of the v_max)
+                asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
+                asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+            }
+            if constexpr (ACT == FR_SIN || ACT == FR_SIN30) {
+                float c;
+                if constexpr (ACT == FR_SIN30) {
+                    // the reduction without the library's large-argument path: exact to 1e5 rad, i.e. for first-layer
+                    // pre-activations up to 3300 -- coordinates are in [-1, 1]
+                    nerf_sincosf_bounded(mul_rn(30.0f, v0), &v0, &c);
+                    nerf_sincosf_bounded(mul_rn(30.0f, v1), &v1, &c);
+                } else {
+                    nerf_sincosf_bounded(v0, &v0, &c);
+                    nerf_sincosf_bounded(v1, &v1, &c);
+                }
+            }
+            unsigned tm[3];
+            split2<3>(v0, v1, tm);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) X[p][s][jp] = tm[p];
+        }
+}
+
+template <int N, int NKS>
+__device__ __forceinline__ void vals_to_frags(const float (&v)[N], u32x4 (&X)[3][NKS]) {
+    static_assert(N % 8 == 0 && N / 8 <= NKS, "whole k-steps");
+#pragma unroll
+    for (int ks = 0; ks < N / 8; ++ks) {
+        u32x4 w[3];
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            unsigned tm[3];
+            split2<3>(v[8 * ks + 2 * jp], v[8 * ks + 2 * jp + 1], tm);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) w[p][jp] = tm[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) X[p][ks] = w[p];
+    }
+}
+
+// DENSITY_ONLY (colors == NULL): the stream ends with the layer that holds the density row -- the coarse pass of a
+// hierarchical render without gradients feeds only the re-sampling.
+template <int MODEL, bool DENSITY_ONLY>
+__global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
+    using G = Geo<MODEL>;
+    constexpr auto bias_tile0 = [](int l) { return G::bias_tile0(l); };
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    float* bias_lds = reinterpret_cast<float*>(smem + NBUF * CHUNK_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4;
+
+    // Ordinary loads first (inputs, bias image -> LDS): once LDS-DMA loads are in flight the compiler
+    // waits for ALL of them at the first use of an ordinary load's result.
+    const float* bias_g = reinterpret_cast<const float*>(a.img + G::IMG_BYTES);
+    for (int i = tid; i < (int)G::BIAS_FLOATS; i += WG_THREADS) bias_lds[i] = bias_g[i];
+
+    // all four lane groups load the sample of lane & 15
+    const size_t m = (size_t)blockIdx.x * WG_SAMPLES + wave * 16 + (lane & 15);
+    const bool valid = m < (size_t)a.M;
+    float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    if (valid) {
+#pragma clang fp contract(off)  // o + t*d must not become an FMA (same positions as the fp32 path)
+        if (a.points) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                x[c] = a.points[m * 3 + c];
+                d[c] = a.dirs[m * 3 + c];
+            }
+        } else {
+            const size_t ray = m / (size_t)a.S;
+            const float ts = a.t_per_ray ? a.t[m] : a.t[m - ray * (size_t)a.S];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                d[c] = a.rays_d[ray * 3 + c];
+                x[c] = norm_coord16(add_rn(a.rays_o[ray * 3 + c], mul_rn(ts, d[c])), a.nearf, a.spanf);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing ordinary is outstanding from here on
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int DENSITY_LAYER = MODEL == NERF_MODEL_NERF ? 9 : 8;
+    // chunks of the stream this variant reads (nothing may be in flight towards LDS when the workgroup ends)
+    constexpr int NCHUNK_RUN = DENSITY_ONLY ? G::chunk0(DENSITY_LAYER + 1) : G::NCHUNK;
+    // chunks behind layer l's last one, as mma_layer's TAIL
+    constexpr auto tail = [](int l) { return NCHUNK_RUN - G::chunk0(l + 1) < 2 ? NCHUNK_RUN - G::chunk0(l + 1) : 2; };
+    Ring ring{a.img, smem, 0, 16u * (unsigned)tid, wave, NCHUNK_RUN, (int)G::IMG_BYTES};
+#pragma unroll
+    for (int c = 0; c < AHEAD; ++c) ring_issue(ring, c);   // these land while the encodings below are computed
+    __builtin_amdgcn_sched_barrier(0);
+
+    // First layer's encoding fragments in the slot order k_column16() gives the weight image.
+    u32x4 E0[3][2];
+    if constexpr (MODEL == NERF_MODEL_NERF) {
+        float v[16];
+        const float sa = (float)(1 << (2 * q)), sc = (float)(256 << (q >> 1));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sn, cs;
+            nerf_sincosf(mul_rn(sa, x[c]), &sn, &cs);
+            v[c] = sn;
+            v[3 + c] = cs;
+            nerf_sincosf(mul_rn(2.0f * sa, x[c]), &sn, &cs);
+            v[6 + c] = sn;
+            v[9 + c] = cs;
+            nerf_sincosf(mul_rn(sc, x[c]), &sn, &cs);
+            v[12 + c] = (q & 1) ? cs : sn;
+        }
+        v[15] = q == 0 ? x[0] : q == 1 ? x[1] : q == 2 ? x[2] : 0.0f;
+        vals_to_frags<16, 2>(v, E0);
+    } else {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = q == 0 ? x[c] : 0.0f;
+        vals_to_frags<8, 2>(v, E0);
+    }
+    // publish chunk 0 and the bias image: own pieces of chunk 0 landed (chunks 1, 2 stay in flight),
+    // own LDS writes done, then the barrier
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * PER_CHUNK) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f32x4 acc[NOT_MAX];
+    u32x4 X[3][8];
+    // direction encoding (both models: nerf/encoding.py with 4 frequencies): lane group q owns frequency q and the raw
+    // component q.  Only computed in front of the layer that reads it.
+    auto direction_frags = [&](u32x4 (&DE)[3][2]) {
+        float v[8];
+        const float s0 = (float)(1 << q);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nerf_sincosf(mul_rn(s0, d[c]), &v[c], &v[3 + c]);
+        v[6] = q == 0 ? d[0] : q == 1 ? d[1] : q == 2 ? d[2] : 0.0f;
+        v[7] = 0.0f;
+        vals_to_frags<8, 2>(v, DE);
+    };
+    float dens;
+
+    if constexpr (MODEL == NERF_MODEL_NERF) {
+        init_bias<16>(acc, bias_lds, bias_tile0(0), q);
+        mma_layer<16, 0, 2, tail(0)>(ring, lane, acc, X, E0);
+        to_frags<8, FR_RELU>(acc, X);
+#pragma unroll 1
+        for (int l = 1; l <= 4; ++l) {
+            init_bias<16>(acc, bias_lds, 16 * l, q);
+            mma_layer<16, 8, 0, tail(4)>(ring, lane, acc, X, E0);
+            to_frags<8, FR_RELU>(acc, X);
+        }
+        // skip layer: [features | position encoding]
+        init_bias<16>(acc, bias_lds, bias_tile0(5), q);
+        mma_layer<16, 8, 2, tail(5)>(ring, lane, acc, X, E0);
+        to_frags<8, FR_RELU>(acc, X);
+#pragma unroll 1
+        for (int l = 6; l <= 8; ++l) {
+            init_bias<16>(acc, bias_lds, 16 * l, q);
+            mma_layer<16, 8, 0, tail(8)>(ring, lane, acc, X, E0);
+            to_frags<8, FR_RELU>(acc, X);
+        }
+        // block2.8: 256 feature rows (no activation) + the density row (first row of the 17th tile)
+        init_bias<17>(acc, bias_lds, bias_tile0(9), q);
+        if constexpr (DENSITY_ONLY) {
+            mma_layer<17, 8, 0, 0, 16>(ring, lane, acc, X, E0);
+            if (valid && q == 0) a.density[m] = fmaxf(acc[16][0], 0.0f);
+            return;
+        }
+        mma_layer<17, 8, 0, tail(9)>(ring, lane, acc, X, E0);
+        dens = fmaxf(acc[16][0], 0.0f);
+        to_frags<8, FR_NONE>(acc, X);
+        // rgb head: [features | direction encoding] -> 128, ReLU
+        u32x4 DE[3][2];
+        direction_frags(DE);
+        init_bias<8>(acc, bias_lds, bias_tile0(10), q);
+        mma_layer<8, 8, 1, tail(10)>(ring, lane, acc, X, DE);
+        to_frags<4, FR_RELU>(acc, X);
+        init_bias<1>(acc, bias_lds, bias_tile0(11), q);
+        mma_layer<1, 4, 0, 0>(ring, lane, acc, X, DE);
+    } else {
+        // nerf/models.py:185-203: sin(30 (W0 x + b0)), seven sin(W h + b) layers, then feature_remap + density_branch
+        // as one 17-tile layer, the 283 -> 128 sine layer of the rgb head and its 128 -> 3 output layer
+        init_bias<16>(acc, bias_lds, bias_tile0(0), q);
+        mma_layer<16, 0, 1, tail(0)>(ring, lane, acc, X, E0);
+        to_frags<8, FR_SIN30>(acc, X);
+#pragma unroll 1
+        for (int l = 1; l <= 7; ++l) {
+            init_bias<16>(acc, bias_lds, 16 * l, q);
+            mma_layer<16, 8, 0, tail(7)>(ring, lane, acc, X, E0);
+            to_frags<8, FR_SIN>(acc, X);
+        }
+        init_bias<17>(acc, bias_lds, bias_tile0(8), q);
+        if constexpr (DENSITY_ONLY) {
+            mma_layer<17, 8, 0, 0, 16>(ring, lane, acc, X, E0);
+            if (valid && q == 0) a.density[m] = fmaxf(acc[16][0], 0.0f) * 10.0f;
+            return;
+        }
+        mma_layer<17, 8, 0, tail(8)>(ring, lane, acc, X, E0);
+        dens = fmaxf(acc[16][0], 0.0f) * 10.0f;           // relu(sigma) * sigma_mul (models.py:193)
+        to_frags<8, FR_NONE>(acc, X);
+        u32x4 DE[3][2];
+        direction_frags(DE);
+        init_bias<8>(acc, bias_lds, bias_tile0(9), q);
+        mma_layer<8, 8, 1, tail(9)>(ring, lane, acc, X, DE);
+        to_frags<4, FR_SIN>(acc, X);
+        init_bias<1>(acc, bias_lds, bias_tile0(10), q);
+        mma_layer<1, 4, 0, 0>(ring, lane, acc, X, DE);
+    }
+
+    if (valid && q == 0) {  // rows 0..2 of the last tile and the density row sit in lane group 0
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.colors[m * 3 + c] = dev::sigmoidf_(acc[0][c]);
+        a.density[m] = dens;
+    }
+}
+
+template <int MODEL>
+int pack_image(const float* const* params, void* packed, void* stream, const char* who) {
+    using G = Geo<MODEL>;
+    PackArgs a;
+    for (int i = 0; i < NERF_NUM_PARAM_TENSORS; ++i) {
+        if (!params[i]) return nerf_fail(NERF_E_NULL, "%s: params[%d] is NULL", who, i);
+        a.src[i] = params[i];
+    }
+    a.dst = static_cast<unsigned char*>(packed);
+    for (int l = 0; l < NL_MAX; ++l) a.layers[l] = Net<MODEL>::LAYERS[l];
+    for (int l = 0; l <= NL_MAX; ++l) {
+        a.chunk0[l] = G::chunk0(l < G::NL ? l : G::NL);
+        a.bias_tile0[l] = G::bias_tile0(l < G::NL ? l : G::NL);
+    }
+    const int pieces = G::NCHUNK * CHUNK_UNITS * 64;
+    pack_x3i_kernel<MODEL><<<(pieces + 255) / 256, 256, 0, (hipStream_t)stream>>>(a);
+    return nerf_check_launch(who);
+}
+
+template <int MODEL>
+int launch_fwd(const FwdArgs& a, int64_t M, void* stream, const char* who) {
+    const int64_t groups = ceil_div64(M, WG_SAMPLES);
+    if (groups >= (1ll << 31)) return nerf_fail(NERF_E_ARG, "%s: too many samples", who);
+    if (a.colors) {
+        if (int rc = nerf_set_lds(fwd_x3i_kernel<MODEL, false>, LDS_BYTES)) return rc;
+        fwd_x3i_kernel<MODEL, false><<<(unsigned)groups, WG_THREADS, LDS_BYTES, (hipStream_t)stream>>>(a);
+    } else {
+        if (int rc = nerf_set_lds(fwd_x3i_kernel<MODEL, true>, LDS_BYTES)) return rc;
+        fwd_x3i_kernel<MODEL, true><<<(unsigned)groups, WG_THREADS, LDS_BYTES, (hipStream_t)stream>>>(a);
+    }
+    return nerf_check_launch(who);
+}
+
+}  // namespace
+
+extern "C" size_t nerf_mlp_packed_bf16x3_bytes(int model) {
+    return model == NERF_MODEL_NERF ? Geo<NERF_MODEL_NERF>::PACKED_BYTES : model == NERF_MODEL_SIREN ? Geo<NERF_MODEL_SIREN>::PACKED_BYTES : 0;
+}
+
+extern "C" int nerf_mlp_pack_bf16x3(int model, const float* const* params, void* packed, void* stream) {
+    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "nerf_mlp_pack_bf16x3: unknown model %d", model);
+    NERF_REQUIRE_PTR(params);
+    NERF_REQUIRE_PTR(packed);
+    return model == NERF_MODEL_NERF ? pack_image<NERF_MODEL_NERF>(params, packed, stream, "nerf_mlp_pack_bf16x3")
+                                    : pack_image<NERF_MODEL_SIREN>(params, packed, stream, "nerf_mlp_pack_bf16x3");
+}
+
+extern "C" int nerf_mlp_fwd_bf16x3(int model, const void* packed, int64_t M, const float* points, const float* dirs,
+                                   const float* rays_o, const float* rays_d, const float* t, int S, int t_per_ray,
+                                   double near, double far, float* colors, float* density, void* stream) {
+    const char* who = "nerf_mlp_fwd_bf16x3";
+    NERF_REQUIRE(model == NERF_MODEL_NERF || model == NERF_MODEL_SIREN, "%s: unknown model %d", who, model);
+    if (M < 0) return nerf_fail(NERF_E_ARG, "%s: M=%lld < 0", who, (long long)M);
+    if (M == 0) return NERF_OK;
+    if (!packed || !density) return nerf_fail(NERF_E_NULL, "%s: packed and density must not be NULL", who);
+    if (points) {
+        if (!dirs) return nerf_fail(NERF_E_NULL, "%s: dirs is NULL", who);
+    } else {
+        if (!rays_o || !rays_d || !t) return nerf_fail(NERF_E_NULL, "%s: rays_o, rays_d and t must not be NULL without points", who);
+        if (S < 1 || M % S != 0) return nerf_fail(NERF_E_ARG, "%s: M=%lld is not a multiple of S=%d", who, (long long)M, S);
+        if (far == near) return nerf_fail(NERF_E_ARG, "%s: near == far", who);
+    }
+    FwdArgs a{static_cast<const unsigned char*>(packed), M, points, dirs, rays_o, rays_d, t, S, t_per_ray,
+              (float)near, (float)(far - near), colors, density};
+    return model == NERF_MODEL_SIREN ? launch_fwd<NERF_MODEL_SIREN>(a, M, stream, who) : launch_fwd<NERF_MODEL_NERF>(a, M, stream, who);
+}
