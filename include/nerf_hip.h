@@ -149,9 +149,9 @@ int nerf_mlp_fwd_bf16(int model, const void* packed, int64_t M, const float* poi
  * Same computation as nerf_mlp_fwd without a workspace and same arguments as nerf_mlp_fwd_bf16, at fp32 accuracy: every weight, encoding value and
  * activation is the exact sum of three bf16 terms (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)) and every
  * product is formed from the six term products w0x0 + w0x1 + w0x2 + w1x0 + w1x1 + w2x0, each exact in the fp32
- * accumulator of v_mfma_f32_32x32x16_bf16; what is dropped is below 2^-24 of the product.  The results differ from
- * nerf_mlp_fwd's by fp32 accumulation rounding only and hold the same 1e-5 bar against the reference; six bf16 MFMAs
- * (32 cycles per 16 k) replace eight fp32 ones (64 cycles per 2 k).  `packed` is an image of
+ * accumulator of v_mfma_f32_16x16x32_bf16 (16-sample tiles, csrc/mlp_x3i.hip); what is dropped is below 2^-24 of the
+ * product.  The results differ from nerf_mlp_fwd's by fp32 accumulation rounding only and hold the same 1e-5 bar
+ * against the reference; six bf16 MFMAs take 0.375 of the matrix-pipe time of the fp32 MFMAs they replace.  `packed` is an image of
  * nerf_mlp_packed_bf16x3_bytes(model) BYTES built by nerf_mlp_pack_bf16x3 (re-run after every parameter change). */
 size_t nerf_mlp_packed_bf16x3_bytes(int model);                /* 0 for an unknown model */
 int nerf_mlp_pack_bf16x3(int model, const float* const* params, void* packed, void* stream);

@@ -183,22 +183,28 @@ struct Ring {
     const unsigned char* img;
     unsigned char* lds;
     int next;        // chunk the next buffer switch hands out
-    unsigned voff;   // this thread's byte offset inside a slice of a chunk (16 * tid)
+    unsigned voff;   // this thread's byte offset inside a chunk: its wave's slice, 16 bytes per lane
     int wave;
     int nchunk, img_bytes;
 };
 
-// piece i (16 bytes per thread) of a chunk: global memory -> LDS without staging registers (buffer form of the LDS-DMA:
-// image base and size in a scalar resource, chunk and slice in the scalar offset, 16 * tid in the one vector offset)
+// piece i (16 bytes per thread) of a chunk: global memory -> LDS without staging registers.  Buffer form of the LDS-DMA:
+// image base and size in a scalar resource, the chunk in the scalar offset, the thread's place (its wave's slice of
+// PER_CHUNK KiB, 16 bytes per lane) in the one vector offset, the piece in the instruction's immediate offset -- which
+// the hardware adds to the LDS address as well, so that the LDS base (M0) changes once per chunk, not once per piece.
 __device__ __forceinline__ void ring_issue_piece(const Ring& r, int chunk, int i) {
     if (chunk < r.nchunk) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(r.img), 0, r.img_bytes, 0x00020000);
-        unsigned char* dst = r.lds + (chunk & (NBUF - 1)) * CHUNK_BYTES + 16 * 64 * r.wave;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + i * 16 * WG_THREADS), 16,
-                                                 (int)r.voff, chunk * CHUNK_BYTES + i * 16 * WG_THREADS, 0, 0);
+        unsigned char* dst = r.lds + (chunk & (NBUF - 1)) * CHUNK_BYTES + PER_CHUNK * 1024 * r.wave;
+        auto lds = (__attribute__((address_space(3))) void*)dst;
+        // (the immediate must be a literal for the builtin)
+        if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, (int)r.voff, chunk * CHUNK_BYTES, 0, 0);
+        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, (int)r.voff, chunk * CHUNK_BYTES, 1024, 0);
+        if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, (int)r.voff, chunk * CHUNK_BYTES, 2048, 0);
     }
 }
+static_assert(PER_CHUNK == 3, "ring_issue_piece spells out its immediates");
 __device__ __forceinline__ void ring_issue(const Ring& r, int chunk) {
 #pragma unroll
     for (int i = 0; i < PER_CHUNK; ++i) ring_issue_piece(r, chunk, i);
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
     constexpr int NCHUNK_RUN = DENSITY_ONLY ? G::chunk0(DENSITY_LAYER + 1) : G::NCHUNK;
     // chunks behind layer l's last one, as mma_layer's TAIL
     constexpr auto tail = [](int l) { return NCHUNK_RUN - G::chunk0(l + 1) < 2 ? NCHUNK_RUN - G::chunk0(l + 1) : 2; };
-    Ring ring{a.img, smem, 0, 16u * (unsigned)tid, wave, NCHUNK_RUN, (int)G::IMG_BYTES};
+    Ring ring{a.img, smem, 0, (unsigned)(PER_CHUNK * 1024 * wave + 16 * lane), wave, NCHUNK_RUN, (int)G::IMG_BYTES};
 #pragma unroll
     for (int c = 0; c < AHEAD; ++c) ring_issue(ring, c);   // these land while the encodings below are computed
     __builtin_amdgcn_sched_barrier(0);

@@ -67,9 +67,9 @@ def test_argument_errors_of_the_optional_paths():
     assert lib.nerf_mlp_fwd_bf16(_hip.MODEL_SIREN, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -1
     assert b"NeRF model only" in lib.nerf_last_error()
     assert lib.nerf_mlp_fwd_bf16(_hip.MODEL_NERF, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -2
-    # three-term mode: three units per weight fragment, every layer starts a new 32 KiB chunk
-    assert lib.nerf_mlp_packed_bf16x3_bytes(_hip.MODEL_NERF) == 124 * 32768 + 86 * 32 * 4
-    assert lib.nerf_mlp_packed_bf16x3_bytes(_hip.MODEL_SIREN) == 107 * 32768 + 78 * 32 * 4      # both models
+    # three-term mode: three 1 KiB units per weight fragment (16 rows x 32 k), chunks of 24 units, 16 bias floats per output tile
+    assert lib.nerf_mlp_packed_bf16x3_bytes(_hip.MODEL_NERF) == 163 * 24576 + 170 * 16 * 4
+    assert lib.nerf_mlp_packed_bf16x3_bytes(_hip.MODEL_SIREN) == 141 * 24576 + 154 * 16 * 4      # both models
     assert lib.nerf_mlp_packed_bf16x3_bytes(7) == 0
     assert lib.nerf_mlp_fwd_bf16x3(7, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -1
     assert lib.nerf_mlp_fwd_bf16x3(_hip.MODEL_SIREN, None, 8, None, None, None, None, None, 0, 0, 0.0, 1.0, None, None, None) == -2
