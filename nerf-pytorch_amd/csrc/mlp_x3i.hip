@@ -30,14 +30,21 @@
 // wave having read at least one unit of chunk c, frees the buffer of chunk c-1 -- and chunk c+3 is requested into that
 // buffer, one piece per following unit.  The fragment reads in flight at the barrier are untouched by it.
 //
-// Measured and not kept (all with results bit for bit unchanged): waves 4-7 trailing waves 0-3 by one or two chunks so
-// that the splitting epilogues of the two waves of a SIMD do not coincide (a barrier per chunk keeps the wave groups
-// within one chunk of each other whatever the lag: 3 % slower); the split of finished tiles placed between the MFMAs of
-// the layer's last k-step (same cycles: there the 13 vector instructions per value pair are 4-5 per MFMA, and only 2
-// per MFMA issue in its shadow -- tests/micro/coexec16.hip); LDS-DMA pieces of the two waves of a SIMD at different
-// units; request distance 4 and 5 chunks; 8 fragment reads in flight.  Where the cycles go (counters, 1,048,576
-// samples): the matrix pipe is busy 0.76 of them; the rest is the LDS-DMA instructions (3 per thread and chunk, some
-// 40-60 cycles of issue each: 12 %) and the splitting epilogues (9 %).
+// Measured and not kept (all with results bit for bit unchanged; cycles = GRBM_GUI_ACTIVE of the launch):
+//   * waves 4-7 trailing waves 0-3 by one or two chunks, so that the splitting epilogues of the two waves of a SIMD do
+//     not coincide: a barrier per chunk keeps the wave groups within one chunk of each other whatever the lag; 3 % slower;
+//   * the split of finished tiles placed between the MFMAs of the layer's last k-step: same cycles;
+//   * the plain 256 -> 256 layers tile-major (all k-steps of output tile 0, then of tile 1, ...; two accumulator tiles
+//     instead of 16, a second set of fragment registers, 256 registers without spills) with the previous tile's split
+//     spread over the next tile's 48 MFMAs, one or two vector instructions after every second unit: + 6-11 % cycles;
+//     the same loop with those vector instructions removed (wrong results) takes the cycles of the k-step-major
+//     kernel WITH its epilogues.  In tests/micro/coexec16.hip two vector instructions per MFMA issue in its shadow;
+//     in this loop (a fragment read and a counted wait per unit beside the MFMAs) they are paid in full, and packed
+//     fp32 ones (v_pk_add_f32: 4.7 cycles alone, a whole 16-cycle MFMA slot beside MFMAs) more than that;
+//   * LDS-DMA pieces of the two waves of a SIMD at different units; request distance 4 and 5 chunks; 8 fragment reads in
+//     flight; the waits for landed pieces removed (still correct: the pieces are never late).
+// Where the cycles go (counters, 1,048,576 samples per launch): the matrix pipe is busy 0.76 of them.  Without the
+// LDS-DMA instructions (stale weights, timing only) the kernel is 12 % faster, without the splits 7 %.
 #include "bf16_common.h"
 
 using namespace bf16k;

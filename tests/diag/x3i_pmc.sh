@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 run() {
     local name=$1; shift
     rm -rf "$OUT/$name"
-    VARIANTS=0 timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$OUT/$name" -o p --output-format csv -- python3 tests/diag/x3i_variants.py ${MODEL_ARG:-} > /dev/null 2> "$OUT/$name.log" || return 1
+    timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$OUT/$name" -o p --output-format csv -- python3 tests/diag/bf16x3_speed.py ${MODEL_ARG:-} > /dev/null 2> "$OUT/$name.log" || return 1
     python3 profiles/summarize_pmc.py "$OUT/$name" > "$OUT/x3i_pmc_$name.csv"
 }
 run sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE &&

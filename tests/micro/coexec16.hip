@@ -28,7 +28,7 @@ __device__ __forceinline__ void filler(float (&v)[8], int j, float x) {
 
 // WAVES waves per workgroup (4: one per SIMD, 8: two), one workgroup per CU.  Per iteration 48 MFMAs in runs of RUN on one
 // accumulator of 16, NV fillers after every MFMA.
-template <int WAVES, int RUN, int NV, int KIND>
+template <int WAVES, int RUN, int NV, int KIND, bool MFMA = true>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void chain(float* out, int iters, float x) {
     f32x4 acc[16];
     for (int i = 0; i < 16; ++i) for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void chain(float* out, int i
     for (int it = 0; it < iters; ++it)
 #pragma unroll
         for (int u = 0; u < 48; ++u) {
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[(u / RUN) & 15]) : "v"(a), "v"(b));
+            if constexpr (MFMA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[(u / RUN) & 15]) : "v"(a), "v"(b));
 #pragma unroll
             for (int j = 0; j < NV; ++j) filler<KIND>(v, j, x);
         }
@@ -64,12 +64,15 @@ int main() {
     const int it = 10000;   // 480,000 MFMAs per wave = 7.7 M cycles at 16 each (3.2 ms at 2.4 GHz); x 2 with two waves per SIMD
 #define ROW(W, RUN, NV, KIND) printf("%d waves/SIMD, runs of %d, %d fillers of kind %d per MFMA: %.3f ms\n", W / 4, RUN, NV, KIND, timed([&] { chain<W, RUN, NV, KIND><<<256, 64 * W>>>(out, it / (W / 4), 1e-3f); }))
     // the same number of MFMAs per SIMD in every row (two waves: half the iterations each)
-    ROW(4, 3, 0, 0); ROW(8, 3, 0, 0); ROW(8, 1, 0, 0); ROW(8, 6, 0, 0);
+    ROW(4, 3, 0, 0); ROW(8, 3, 0, 0); ROW(8, 1, 0, 0); ROW(8, 6, 0, 0); ROW(4, 48, 0, 0); ROW(8, 48, 0, 0); ROW(8, 48, 1, 0); ROW(8, 3, 1, 0);
     ROW(4, 3, 1, 0); ROW(4, 3, 2, 0); ROW(4, 3, 4, 0);
     ROW(8, 3, 1, 0); ROW(8, 3, 2, 0); ROW(8, 3, 4, 0); ROW(8, 3, 6, 0);
     ROW(8, 3, 2, 1); ROW(8, 3, 4, 1);
     ROW(8, 3, 1, 2); ROW(8, 3, 2, 2);
     ROW(8, 3, 2, 3); ROW(8, 3, 4, 3);
     ROW(8, 3, 1, 4); ROW(8, 3, 2, 4);
+    // the fillers alone (no MFMAs): cycles per instruction = ms * clock / (480,000 * NV) per SIMD
+#define VROW(W, NV, KIND) printf("%d waves/SIMD, no MFMAs, %d fillers of kind %d per slot: %.3f ms\n", W / 4, NV, KIND, timed([&] { chain<W, 3, NV, KIND, false><<<256, 64 * W>>>(out, it / (W / 4), 1e-3f); }))
+    VROW(4, 4, 0); VROW(8, 4, 0); VROW(8, 4, 1); VROW(4, 2, 2); VROW(8, 2, 2); VROW(8, 4, 3);
     return 0;
 }
