@@ -3,6 +3,7 @@
 #   bash profiles/collect.sh r3            (everything)
 #   bash profiles/collect.sh r3 modes      (only the bench lines of the other modes and the HBM-bound kernels)
 #   bash profiles/collect.sh r3 pmc        (only the counter passes)
+#   bash profiles/collect.sh r3 stats      (only the rocprofv3 --kernel-trace --stats runs)
 # writes gpurun_out/<tag>/prof/<tag>_*.csv|json|jsonl; copy what should be judged into profiles/.
 #   * rocprofv3 --kernel-trace --stats of the default bench command and of its other modes
 #   * separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ) of the single-pass workload, where every
@@ -22,13 +23,14 @@ stats() {   # name, bench arguments...
     cp "$(find "$OUT/kt_$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_${name}_kernel_stats.csv"
 }
 pmc() {     # name, counters...   (NeRF single-pass workload; name "siren_*" profiles the Siren network instead,
-            #                      name "x3_*" the opt-in bf16x3 training kernels of the NeRF network)
+            #                      name "x3_*" the opt-in bf16x3 training kernels of the NeRF network, name "x3i_*" the
+            #                      bf16x3 inference kernel: 32768 rays x 256 samples = 8,388,608 samples per launch)
     local name=$1; shift
     local model=nerf
-    local tp=fp32
-    case "$name" in siren_*) model=siren;; x3_*) tp=bf16x3;; esac
+    local work="--train-precision fp32"
+    case "$name" in siren_*) model=siren;; x3_*) work="--train-precision bf16x3";; x3i_*) work="--mode infer --precision bf16x3 --rays 32768";; esac
     rm -rf "$OUT/pmc_$name"
-    timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$OUT/pmc_$name" -o p --output-format csv -- python3 bench.py --sampling single --model $model --train-precision $tp --steps 3 --warmup 1 --no-cpu-baseline \
+    timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$OUT/pmc_$name" -o p --output-format csv -- python3 bench.py --sampling single --model $model $work --steps 3 --warmup 1 --no-cpu-baseline \
         > /dev/null 2> "$OUT/pmc_$name.log" || return 1
     python3 profiles/summarize_pmc.py "$OUT/pmc_$name" > "$OUT/${TAG}_pmc_$name.csv"
 }
@@ -46,7 +48,10 @@ pmc_all() {
     pmc x3_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE &&
     pmc x3_fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
     pmc x3_write WRITE_SIZE &&
-    echo '{"samples_per_dispatch": 1048576, "command": "rocprofv3 --pmc <counters> -- python3 bench.py --sampling single [--model siren] --steps 3 --warmup 1 --no-cpu-baseline", "unit": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (profiles/summarize_pmc.py means); files named *_pmc_siren_* are the Siren network, *_pmc_x3_* the opt-in bf16x3 training kernels (--train-precision bf16x3)"}' > "$OUT/${TAG}_pmc_meta.json"
+    pmc x3i_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
+    pmc x3i_insts SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE &&
+    pmc x3i_wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE &&
+    echo '{"samples_per_dispatch": 1048576, "command": "rocprofv3 --pmc <counters> -- python3 bench.py --sampling single [--model siren] --steps 3 --warmup 1 --no-cpu-baseline", "unit": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (profiles/summarize_pmc.py means); files named *_pmc_siren_* are the Siren network, *_pmc_x3_* the opt-in bf16x3 training kernels (--train-precision bf16x3), *_pmc_x3i_* the bf16x3 inference kernel (--mode infer --precision bf16x3 --rays 32768: 8,388,608 samples per dispatch)"}' > "$OUT/${TAG}_pmc_meta.json"
 }
 modes() {
     : > "$OUT/${TAG}_bench_modes.jsonl"
@@ -59,6 +64,12 @@ modes() {
 }
 if [ "$ONLY" = modes ]; then
     modes && echo "modes collected in $OUT"
+    exit $?
+fi
+if [ "$ONLY" = stats ]; then
+    stats hier && stats single --steps 6 --warmup 2 --sampling single && stats siren --steps 6 --warmup 2 --sampling single --model siren &&
+    stats x3 --steps 6 --warmup 2 --train-precision bf16x3 && stats x3_single --steps 6 --warmup 2 --sampling single --train-precision bf16x3 &&
+    stats infer_bf16x3 --steps 6 --warmup 2 --mode infer --precision bf16x3 --rays 32768 && echo "kernel statistics collected in $OUT"
     exit $?
 fi
 if [ "$ONLY" = pmc ]; then

@@ -86,6 +86,75 @@ def find_violations(text, slots=2):
     return bad
 
 
+# ---- second guard: the asm MFMAs of the three-term inference kernel ------------------------------------------------
+# csrc/mlp_x3i.hip issues v_mfma_f32_16x16x32_bf16 through inline asm (destination = C operand, in place).  The compiler
+# does not know what the asm statement is, so it inserts none of the wait states the hardware needs between an MFMA and
+# a vector, LDS or memory instruction that reads (or overwrites) its result; the kernel covers the one place where that
+# happens -- the end of a layer -- with s_nop.  This check fails the build if any other instruction than an MFMA
+# accumulating into the same registers touches an asm MFMA's destination within MFMA_WAIT_STATES wait states.
+MFMA_WAIT_STATES = 12      # an 8-pass MFMA's result needs 11 before a vector instruction may read it
+ASM_MFMA = "v_mfma_f32_16x16x32_bf16"
+
+
+def find_mfma_violations(text, need=MFMA_WAIT_STATES):
+    insts, func = [], "?"
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            func = m.group(1)
+            continue
+        body = line.split("//")[0].strip()
+        if not body or body.endswith(":"):
+            continue
+        parts = body.split(None, 1)
+        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        insts.append((func, parts[0], ops, body))
+    bad = []
+    for i, (func, op, ops, body) in enumerate(insts):
+        if op != ASM_MFMA or "x3i" not in func:
+            continue
+        dst = _regs(ops[0])
+        states = 0
+        for f2, op2, ops2, body2 in insts[i + 1:i + 1 + need + 1]:
+            if f2 != func or states >= need:
+                break
+            if op2 == ASM_MFMA:
+                if _regs(ops2[0]) == dst:
+                    break                               # the next link of the same accumulation chain: forwarded in hardware
+                touched = set().union(*[_regs(o.split()[0]) for o in ops2[1:3]])    # A and B operands
+            else:
+                touched = set().union(*[_regs(o.split()[0]) for o in ops2]) if ops2 else set()
+            if touched & dst:
+                bad.append((func, body, body2, states))
+                break
+            states += 1 + (int(ops2[0]) if op2 == "s_nop" and ops2 and ops2[0].isdigit() else 0)
+    return bad
+
+
+def test_mfma_checker_sees_a_read_too_close():
+    sample = """
+0000000000001000 <fwd_x3i_k>:
+	v_mfma_f32_16x16x32_bf16 v[10:13], v[20:23], v[30:33], v[10:13]
+	v_mfma_f32_16x16x32_bf16 v[10:13], v[20:23], v[34:37], v[10:13]
+	v_max_f32_e32 v40, 0, v11
+	v_mfma_f32_16x16x32_bf16 v[50:53], v[20:23], v[30:33], v[50:53]
+	s_nop 15
+	v_max_f32_e32 v41, 0, v51
+	v_mfma_f32_16x16x32_bf16 v[60:63], v[20:23], v[30:33], v[60:63]
+	s_nop 4
+	ds_read_b128 v[60:63], v3
+"""
+    bad = find_mfma_violations(sample)
+    assert len(bad) == 2 and "v11" in bad[0][2] and "ds_read_b128" in bad[1][2]
+
+
+def test_nothing_touches_an_asm_mfma_result_too_early():
+    texts = _device_disassembly()
+    assert sum(len(re.findall(ASM_MFMA, t)) for t in texts) > 0, "the three-term inference kernel was not found in the disassembly"
+    bad = [v for t in texts for v in find_mfma_violations(t)]
+    assert not bad, "\n".join(f"{f}: `{a}` then after {n} wait states `{b}`" for f, a, b, n in bad[:10])
+
+
 def test_checker_sees_the_hazard_pattern():
     sample = """
 0000000000001000 <k>:
