@@ -91,7 +91,10 @@ struct Geo {
 };
 constexpr int NBIAS_TILES_MAX = 170;                       // LDS room for the bias image of either model
 static_assert(Geo<NERF_MODEL_NERF>::NBIAS_TILES == 170 && Geo<NERF_MODEL_SIREN>::NBIAS_TILES <= NBIAS_TILES_MAX, "bias image");
-constexpr int LDS_BYTES = NBUF * CHUNK_BYTES + NBIAS_TILES_MAX * 16 * 4;
+// LDS: the 256-entry sine/cosine table of the sine activations (first 2 KiB: its reads address it through the
+// instruction's offset alone), the ring, the bias image
+constexpr int TAB_BYTES = dev::SINCOS_TAB_FLOATS * 4;
+constexpr int LDS_BYTES = TAB_BYTES + NBUF * CHUNK_BYTES + NBIAS_TILES_MAX * 16 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
 
 // Input column of weight element (k-step ks, lane group q, fragment element j) of layer L, or -1.
@@ -309,36 +312,43 @@ __device__ __forceinline__ void mma_layer(Ring& r, int lane, f32x4 (&acc)[NOT_MA
 }
 
 // accumulator tiles -> B fragments of the next layer (one k-step per PAIR of 16-feature tiles), through the layer's
-// activation: FR_SIN is sin(z) of a hidden sine layer (nerf/models.py:89-90 with w0 = 1), FR_SIN30 the first sine layer's sin(30 z)
+// activation: FR_SIN is sin(z) of a hidden sine layer (nerf/models.py:89-90 with w0 = 1), FR_SIN30 the first sine layer's
+// sin(30 z).  The sines take the table form of the fp32 kernels' sine epilogues (csrc/sincos.h: 6.2e-8 absolute for
+// |x| <= 1e5; pre-activations of sine layers fed by sines are bounded by sum|w| + |b|, first-layer ones by 30 times
+// that with coordinates in [-1, 1]): 8 vector instructions and a table read per value where the polynomial form has
+// 25 -- the epilogues run while no MFMA does, so every one of them is exposed.
 enum FragAct { FR_NONE = 0, FR_RELU = 1, FR_SIN = 2, FR_SIN30 = 3 };
 template <int NPAIR, int ACT>
 __device__ __forceinline__ void to_frags(const f32x4 (&acc)[NOT_MAX], u32x4 (&X)[3][8]) {
 #pragma unroll
-    for (int s = 0; s < NPAIR; ++s)
+    for (int s = 0; s < NPAIR; ++s) {
+        f32x2 v[4];
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) v[jp] = f32x2{acc[2 * s + (jp >> 1)][2 * (jp & 1)], acc[2 * s + (jp >> 1)][2 * (jp & 1) + 1]};
+        if constexpr (ACT == FR_SIN || ACT == FR_SIN30) {
+            dev::SinCosPair pr[4];   // the table reads of the four pairs in flight together
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp)
+                dev::sincos_tab_issue(ACT == FR_SIN30 ? f32x2{mul_rn(30.0f, v[jp][0]), mul_rn(30.0f, v[jp][1])} : v[jp], pr[jp]);
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                f32x2 cs;
+                dev::sincos_tab_finish(pr[jp], v[jp], cs);
+            }
+        }
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-            float v0 = acc[2 * s + (jp >> 1)][2 * (jp & 1)], v1 = acc[2 * s + (jp >> 1)][2 * (jp & 1) + 1];
+            float v0 = v[jp][0], v1 = v[jp][1];
             if constexpr (ACT == FR_RELU) {   // (fmaxf puts a canonicalising v_max v, v, v in front of the v_max)
                 asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
                 asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
-            }
-            if constexpr (ACT == FR_SIN || ACT == FR_SIN30) {
-                float c;
-                if constexpr (ACT == FR_SIN30) {
-                    // the reduction without the library's large-argument path: exact to 1e5 rad, i.e. for first-layer
-                    // pre-activations up to 3300 -- coordinates are in [-1, 1]
-                    nerf_sincosf_bounded(mul_rn(30.0f, v0), &v0, &c);
-                    nerf_sincosf_bounded(mul_rn(30.0f, v1), &v1, &c);
-                } else {
-                    nerf_sincosf_bounded(v0, &v0, &c);
-                    nerf_sincosf_bounded(v1, &v1, &c);
-                }
             }
             unsigned tm[3];
             split2<3>(v0, v1, tm);
 #pragma unroll
             for (int p = 0; p < 3; ++p) X[p][s][jp] = tm[p];
         }
+    }
 }
 
 template <int N, int NKS>
@@ -366,7 +376,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
     using G = Geo<MODEL>;
     constexpr auto bias_tile0 = [](int l) { return G::bias_tile0(l); };
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    float* bias_lds = reinterpret_cast<float*>(smem + NBUF * CHUNK_BYTES);
+    unsigned char* ring_lds = smem + TAB_BYTES;
+    float* bias_lds = reinterpret_cast<float*>(ring_lds + NBUF * CHUNK_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4;
@@ -375,6 +386,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
     // waits for ALL of them at the first use of an ordinary load's result.
     const float* bias_g = reinterpret_cast<const float*>(a.img + G::IMG_BYTES);
     for (int i = tid; i < (int)G::BIAS_FLOATS; i += WG_THREADS) bias_lds[i] = bias_g[i];
+    if constexpr (MODEL == NERF_MODEL_SIREN)
+        if (tid < NERF_SINCOS_TABLE_ENTRIES) dev::load_sincos_table(reinterpret_cast<float*>(smem), tid);
 
     // all four lane groups load the sample of lane & 15
     const size_t m = (size_t)blockIdx.x * WG_SAMPLES + wave * 16 + (lane & 15);
@@ -405,7 +418,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
     constexpr int NCHUNK_RUN = DENSITY_ONLY ? G::chunk0(DENSITY_LAYER + 1) : G::NCHUNK;
     // chunks behind layer l's last one, as mma_layer's TAIL
     constexpr auto tail = [](int l) { return NCHUNK_RUN - G::chunk0(l + 1) < 2 ? NCHUNK_RUN - G::chunk0(l + 1) : 2; };
-    Ring ring{a.img, smem, 0, (unsigned)(PER_CHUNK * 1024 * wave + 16 * lane), wave, NCHUNK_RUN, (int)G::IMG_BYTES};
+    Ring ring{a.img, ring_lds, 0, (unsigned)(PER_CHUNK * 1024 * wave + 16 * lane), wave, NCHUNK_RUN, (int)G::IMG_BYTES};
 #pragma unroll
     for (int c = 0; c < AHEAD; ++c) ring_issue(ring, c);   // these land while the encodings below are computed
     __builtin_amdgcn_sched_barrier(0);
