@@ -185,9 +185,11 @@ int nerf_mlp_bwd_weights(int model, int64_t M, const float* fwd_workspace, float
  * accumulation): same arguments, same workspaces, results within fp32 accumulation rounding of the fp32 kernels'
  * (same 1e-5 bar, gradients included).  `packed` is an image of nerf_mlp_packed_x3_floats(model) FLOATS built by
  * nerf_mlp_pack_x3: the fp32 image of nerf_mlp_pack (so the same pointer also serves nerf_mlp_fwd without a
- * workspace) followed by the three-term planes of every dense layer, forward and transposed.  A workspace written
- * by nerf_mlp_fwd_x3 must be read by nerf_mlp_bwd_data_x3 (its ReLU mask words follow this mode's accumulator
- * columns); nerf_mlp_bwd_weights, or its three-term variant below, then runs on either workspace. */
+ * workspace) followed by the three-term images the kernels of this mode stream (NeRF: the transposed planes of the
+ * data-gradient chain, then the image of nerf_mlp_pack_bf16x3, which the forward -- csrc/mlp_x3i.hip, the inference
+ * kernel with workspace stores -- reads; Siren: forward and transposed planes).  A workspace written by
+ * nerf_mlp_fwd_x3 must be read by nerf_mlp_bwd_data_x3 (the ReLU decisions have this mode's own layout);
+ * nerf_mlp_bwd_weights, or its three-term variant below, then runs on either workspace. */
 size_t nerf_mlp_packed_x3_floats(int model);                   /* 0 for a model without this mode */
 int nerf_mlp_pack_x3(int model, const float* const* params, float* packed, void* stream);
 int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const float* points, const float* dirs,

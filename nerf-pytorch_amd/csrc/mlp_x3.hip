@@ -1,6 +1,8 @@
 // Opt-in TRAINING kernels of the NeRF MLP (nerf/models.py:62-75) and, further down, the Siren MLP (:185-203), with what
 // autograd derives for them (train.py:181), on the
 // bf16 matrix pipe at fp32 accuracy ("bf16x3"): forward with the activation workspace, and the data-gradient chain.
+// The NeRF model's forward is the 16-sample-tile kernel of mlp_x3i.hip (same workspace, its own layout of the ReLU
+// decisions); this file holds its data-gradient chain and both Siren kernels.
 // The default training path stays the fp32 MFMA kernels of mlp_fwd.hip / mlp_bwd.hip; the weight-gradient GEMMs read
 // the same workspaces (nerf_mlp_bwd_weights on fp32 MFMA, or nerf_mlp_bwd_weights_x3 with this file's arithmetic).
 //
@@ -30,6 +32,11 @@
 
 using namespace dev;
 
+// mlp_x3i.hip
+int nerf_x3i_fwd_train(const void* image, int64_t M, const float* points, const float* dirs, const float* rays_o,
+                       const float* rays_d, const float* t, int S, int t_per_ray, double near, double far, float* colors,
+                       float* density, float* workspace, void* stream);
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -38,7 +45,6 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 static_assert(TR == 64 && TPS == 4, "the bf16x3 training kernels are written for 64-row tiles");
 constexpr int X3_THREADS = 512;
-typedef unsigned xmask_t;   // (h > 0) bits of one lane's 32 accumulator registers of a 256-wide layer
 
 // ---- LDS ----------------------------------------------------------------------------------------------
 constexpr int LDPB = 528;                        // bytes per plane row: 256 bf16 + 16 bytes (bank spread of the A reads)
@@ -59,15 +65,7 @@ static_assert(TR * LDG * 4 <= PLANES_BYTES, "fp32 view of the plane area");
 namespace x3 {
 using namespace lay;
 constexpr size_t elems(int Kp, int N) { return (size_t)3 * Kp * N; }
-constexpr size_t F_L0 = 0;
-constexpr size_t F_L1 = F_L0 + elems(PE_P, H);
-constexpr size_t F_L5A = F_L1 + 4 * elems(H, H);
-constexpr size_t F_L5B = F_L5A + elems(H, H);
-constexpr size_t F_L6 = F_L5B + elems(PE_P, H);
-constexpr size_t F_L9 = F_L6 + 3 * elems(H, H);
-constexpr size_t F_L10A = F_L9 + elems(H, H);
-constexpr size_t F_L10B = F_L10A + elems(H, HH);
-constexpr size_t D10 = F_L10B + elems(DE_P, HH);
+constexpr size_t D10 = 0;   // the data-gradient chain's images; the forward streams the ring image of mlp_x3i.hip, which follows them
 constexpr size_t D9 = D10 + elems(HH, H);
 constexpr size_t TOTAL = D9 + 9 * elems(H, H);
 constexpr size_t d_img(int layer) { return D9 + (size_t)(9 - layer) * elems(H, H); }   // layer 1..9
@@ -247,20 +245,39 @@ __device__ __forceinline__ void store_value(unsigned char* planes, int row, int 
         *reinterpret_cast<unsigned short*>(planes + p * PLANE_BYTES + row * LDPB + col * 2) = (unsigned short)w[p];
 }
 
-// Epilogue of a 256-wide layer (two interleaved tiles per wave): activation, mask bits, the fp32 tile to the
-// workspace, the three terms to the planes.  Layers with a ReLU arrive negated (their images are packed as 0 - w): the
-// accumulator's sign bit is the decision "pre-activation > 0" (fwd_epilogue of mlp_device.h has the argument).
-//   MODE 0: forward, no activation          MODE 1: forward, ReLU of the negated accumulator, mask out
+// ReLU decisions (z > 0) of one 256-wide layer for a lane's 32 accumulator elements, as the forward kernel stores them
+// (mlp_x3i.hip: 32 bytes per sample; word 2 q + (ot >> 3) of a sample holds feature 16 ot + 4 q + g at bit
+// 31 - (4 (ot & 7) + g)).  A lane owns two adjacent columns of 16 rows: one word per row, and in every word the same two
+// neighbouring bits, which `shift` moves to bits 31 and 30.
+struct X3Masks {
+    unsigned w[16];   // row of accumulator register g (both tiles)
+    int shift;
+};
+// field: the layer's mask field at this tile's first sample
+__device__ __forceinline__ void x3_load_masks(const float* field, int ncol0, int wrow0, int lane, X3Masks& m) {
+    const int r = lane & 31, h = lane >> 5;
+    const int f0 = ncol0 + 2 * r;                         // the lane's first column; f0 + 1 is in the same word
+    const int word = ((f0 >> 2) & 3) * 2 + (f0 >> 7);
+    m.shift = 4 * ((f0 >> 4) & 7) + (f0 & 3);
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(field, (unsigned)(TR * 32));
+    const int voff = (wrow0 + 4 * h) * 32 + word * 4;
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+        m.w[g] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + ((g & 3) + 8 * (g >> 2)) * 32, 0, 0);
+}
+
+// Epilogue of a 256-wide layer (two interleaved tiles per wave): the fp32 tile to the workspace, the three terms to the
+// planes.
+//   MODE 0: forward, no activation
 //   MODE 2: backward, mask in               MODE 3: backward, rank-1 term (dsig[row] * sigw[col]) then mask in
 //   MODE 4: backward, nothing
 // gout: this tile's [64][256] fp32 rows in the workspace (NULL: not stored).  TO_PLANES false: the last layer of a chain.
 template <int MODE, bool TO_PLANES>
 __device__ __forceinline__ void x3_epilogue(unsigned char* planes, f32x16 (&acc)[2], int ncol0, int wrow0, int lane,
-                                            float* __restrict__ gout, xmask_t* mask_out, xmask_t mask_in,
+                                            float* __restrict__ gout, const X3Masks* mask_in,
                                             const float* dsig_lds, const float* __restrict__ sigw) {
     const int r = lane & 31, h = lane >> 5;
     const int col = ncol0 + 2 * r;
-    unsigned mbits = 0u;
     const __amdgpu_buffer_rsrc_t g_rsrc = make_rsrc(gout, (unsigned)(TR * lay::H * 4));
     const int g_voff = ((wrow0 + 4 * h) * lay::H + col) * 4;
     unsigned char* pl = planes + (wrow0 + 4 * h) * LDPB + col * 2;
@@ -272,16 +289,11 @@ __device__ __forceinline__ void x3_epilogue(unsigned char* planes, f32x16 (&acc)
         float v[2] = {acc[0][g], acc[1][g]};
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            // mask bit of element (g, ni), numbered in the order this loop visits them (the shifts below insert in that
-            // order): at bit 31 - bit of the lane's word
-            const int bit = 2 * g + ni;
-            if constexpr (MODE == 1) {
-                mbits = __builtin_amdgcn_alignbit(mbits, __builtin_bit_cast(unsigned, v[ni]), 31);
-                asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v[ni]) : "v"(v[ni]));
-            }
             if constexpr (MODE == 3) v[ni] = fmaf(dsig_lds[wrow0 + row0 + 4 * h], sw[ni], v[ni]);
             if constexpr (MODE == 2 || MODE == 3) {
-                const int keep = __builtin_amdgcn_sbfe((int)mask_in, 31 - bit, 1);   // 0 or all ones
+                // row g's word, this lane's column pair moved to bits 31 and 30: 0 or all ones
+                const int w = (int)(mask_in->w[g] << mask_in->shift);
+                const int keep = ni == 0 ? (w >> 31) : __builtin_amdgcn_sbfe(w, 30, 1);
                 v[ni] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[ni]) & keep);
             }
         }
@@ -307,9 +319,6 @@ __device__ __forceinline__ void x3_epilogue(unsigned char* planes, f32x16 (&acc)
             store_terms(pl, row0 * LDPB, w);
         }
 #endif
-    }
-    if constexpr (MODE == 1) {
-        if (mask_out) *mask_out = mbits;
     }
 }
 
@@ -430,180 +439,6 @@ __device__ __forceinline__ void x3_copy_stage(const unsigned char* stage0, float
     }
 }
 
-__global__ __launch_bounds__(X3_THREADS, 1) void nerf_fwd_x3_kernel(X3FwdArgs a) {
-    using namespace lay;
-    using namespace lay::nerf;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
-    float* tab = reinterpret_cast<float*>(smem_x3);
-    unsigned char* planes = smem_x3 + SINCOS_TAB_FLOATS * 4;
-    float* xin = reinterpret_cast<float*>(planes + PLANES_BYTES);
-    float* sraw_s = xin + X3_XIN_FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wrow0 = (wave >> 2) * 32, wcol = wave & 3;     // this wave's 32 rows and column group
-    const bool per_sample = tid < 256;                       // the four-threads-per-sample phases
-    const size_t m0 = (size_t)blockIdx.x * TR;
-    const float* __restrict__ pk = a.pk;
-    const __bf16* __restrict__ xi = a.x3;
-    float* ws = a.ws;
-    const size_t Mp = a.Mp;
-    auto wsp = [&](size_t off, int width) -> float* { return ws + off * Mp + m0 * width; };
-    // this lane's ReLU mask word of layer l: 512 words per tile and layer (the footprint of the fp32 kernels' 256 x 64 bits)
-    auto mskp = [&](int l) -> xmask_t* { return reinterpret_cast<xmask_t*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid; };
-    const int smp = (tid & 255) / TPS, q = tid % TPS;
-    // fp32 staging rows of the encodings: bytes 128.. of plane 0's rows (columns 64.. of a plane are unused while the
-    // encoding is a layer's input)
-    unsigned char* stage0 = planes + 128;
-
-    if (per_sample) load_sincos_table(tab, tid);
-    x3_load_inputs(a, m0, xin, tid);
-    const int ncol0 = wcol * 64;
-    X3Pre<2> pre;
-    x3_prefetch<2, PE_P / 16, ACC_BIAS>(xi + x3::F_L0, H, ncol0, lane, pk + BIAS, pre);
-    __syncthreads();
-    const auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-    const bool pe_fast = uniform(xin[6]) * 512.0f <= 9.9e4f;
-    EncCache<10> pec;
-    if (per_sample) {
-        if (pe_fast) {
-            enc_compute<10>(xin + smp * 8, q, pec);
-            x3_enc_store<10>(planes, reinterpret_cast<float*>(stage0 + smp * LDPB), smp, q, pec);
-        } else {
-            x3_enc_slow<10>(planes, reinterpret_cast<float*>(stage0 + smp * LDPB), smp, q, xin + smp * 8);
-        }
-    }
-    __syncthreads();
-    x3_copy_stage<PE_P>(stage0, wsp(WS_PE, PE_P), tid);
-
-    f32x16 acc[2];
-    constexpr size_t EHH = x3::elems(H, H);
-    // L0 (its first weight fragments were requested before the encoding)
-    mma_layer_x3<2, PE_P / 16, ACC_BIAS>(planes, xi + x3::F_L0, H, ncol0, wrow0, lane, acc, pre);
-    x3_prefetch<2, H / 16, ACC_BIAS>(xi + x3::F_L1, H, ncol0, lane, pk + BIAS + H, pre);
-    __syncthreads();
-    x3_epilogue<1, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_H, H), mskp(0), 0, nullptr, nullptr);
-    __syncthreads();
-    static_assert(x3::F_L5A == x3::F_L1 + 4 * EHH && x3::F_L9 == x3::F_L6 + 3 * EHH, "the next layer's image follows");
-#pragma unroll 1
-    for (int l = 1; l <= 4; ++l) {
-        mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L1 + (size_t)(l - 1) * EHH, H, ncol0, wrow0, lane, acc, pre);
-        x3_prefetch<2, H / 16, ACC_BIAS>(xi + x3::F_L1 + (size_t)l * EHH, H, ncol0, lane, pk + BIAS + (l + 1) * H, pre);   // L(l+1), L5A after L4
-        __syncthreads();
-        x3_epilogue<1, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_H + (size_t)l * H, H), mskp(l), 0, nullptr, nullptr);
-        __syncthreads();
-    }
-    // L5: [h4 | pe]
-    mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L5A, H, ncol0, wrow0, lane, acc, pre);
-    x3_prefetch<2, PE_P / 16, ACC_KEEP>(xi + x3::F_L5B, H, ncol0, lane, nullptr, pre);
-    __syncthreads();
-    if (per_sample) {
-        if (pe_fast) x3_enc_store<10>(planes, nullptr, smp, q, pec);
-        else x3_enc_slow<10>(planes, nullptr, smp, q, xin + smp * 8);
-    }
-    __syncthreads();
-    mma_layer_x3<2, PE_P / 16, ACC_KEEP>(planes, xi + x3::F_L5B, H, ncol0, wrow0, lane, acc, pre);
-    x3_prefetch<2, H / 16, ACC_BIAS>(xi + x3::F_L6, H, ncol0, lane, pk + BIAS + 6 * H, pre);
-    __syncthreads();
-    x3_epilogue<1, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_H + 5 * (size_t)H, H), mskp(5), 0, nullptr, nullptr);
-    __syncthreads();
-#pragma unroll 1
-    for (int l = 6; l <= 8; ++l) {
-        mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L6 + (size_t)(l - 6) * EHH, H, ncol0, wrow0, lane, acc, pre);
-        x3_prefetch<2, H / 16, ACC_BIAS>(xi + x3::F_L6 + (size_t)(l - 5) * EHH, H, ncol0, lane, pk + BIAS + (l + 1) * H, pre);   // L9 after L8
-        __syncthreads();
-        x3_epilogue<1, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_H + (size_t)l * H, H), mskp(l), 0, nullptr, nullptr);
-        __syncthreads();
-    }
-    // L9: 256 feature columns on MFMA; the density row is a dot product of h8 with the 257th weight row, taken from
-    // the fp32 copy of h8 that the epilogue above has just written to the workspace (the planes hold it as bf16 terms)
-    mma_layer_x3<2, H / 16, ACC_BIAS>(planes, xi + x3::F_L9, H, ncol0, wrow0, lane, acc, pre);
-    const int nc = wcol * 32;
-    X3Pre<1> pre1;
-    x3_prefetch<1, H / 16, ACC_BIAS>(xi + x3::F_L10A, HH, nc, lane, pk + BIAS10, pre1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // every wave's h8 stores are complete; the planes are free
-    if (per_sample) {
-        const float* h8 = wsp(WS_H + 8 * (size_t)H, H) + (size_t)smp * H;
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int k = 4 * (TPS * i + q);
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(h8 + k);
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + SIGW + k);
-            s += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
-        }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += pk[BIAS_SIG];
-        if (q == 0) {
-            sraw_s[smp] = s;
-            ws[WS_SRAW * Mp + m0 + smp] = s;
-        }
-    }
-    x3_epilogue<0, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_F, H), nullptr, 0, nullptr, nullptr);
-    __syncthreads();
-    // L10: [f | de] -> 128, ReLU
-    {
-        f32x16 acc1[1];
-        mma_layer_x3<1, H / 16, ACC_BIAS>(planes, xi + x3::F_L10A, HH, nc, wrow0, lane, acc1, pre1);
-        x3_prefetch<1, DE_P / 16, ACC_KEEP>(xi + x3::F_L10B, HH, nc, lane, nullptr, pre1);
-        __syncthreads();
-        unsigned char* stage_de = planes + 128;   // columns 64.. are free: the direction encoding is 32 wide
-        float* st = reinterpret_cast<float*>(stage_de + smp * LDPB);
-        if (per_sample) {
-            if (uniform(xin[7]) * 8.0f <= 9.9e4f) {
-                EncCache<4> dec;
-                enc_compute<4>(xin + smp * 8 + 3, q, dec);
-                x3_enc_store<4>(planes, st, smp, q, dec);
-            } else {
-                x3_enc_slow<4>(planes, st, smp, q, xin + smp * 8 + 3);
-            }
-        }
-        __syncthreads();
-        x3_copy_stage<DE_P>(stage_de, wsp(WS_DE, DE_P), tid);
-        mma_layer_x3<1, DE_P / 16, ACC_KEEP>(planes, xi + x3::F_L10B, HH, nc, wrow0, lane, acc1, pre1);
-        __syncthreads();
-        // epilogue: g = max(0, -n) as fp32 into the plane area (viewed as [64][LDG] floats) for the head, and to the workspace
-        float* gt = reinterpret_cast<float*>(planes);
-        float* gg = wsp(WS_G, HH);
-        const int col = nc + (lane & 31);
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int row = wrow0 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-            float v = acc1[0][g];
-            asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v) : "v"(v));
-            gt[row * LDG + col] = v;
-            gg[(size_t)row * HH + col] = v;
-        }
-        __syncthreads();
-        // L11 + sigmoid, density = relu(raw)
-        if (per_sample) {
-            float z[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = 4 * (TPS * i + q);
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(gt + smp * LDG + k);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + W11 + c * HH + k);
-                    z[c] += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                z[c] += __shfl_xor(z[c], 1);
-                z[c] += __shfl_xor(z[c], 2);
-            }
-            const size_t m = m0 + smp;
-            if (q == 0 && m < (size_t)a.M) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) a.colors[m * 3 + c] = sigmoidf_(z[c] + pk[BIAS11 + c]);
-                a.density[m] = fmaxf(sraw_s[smp], 0.0f);
-            }
-        }
-    }
-}
-
 // ---- data gradient ----------------------------------------------------------------------------------------
 struct X3BwdArgs {
     const float* pk;
@@ -634,7 +469,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void nerf_dgrad_x3_kernel(X3BwdArgs 
     float* bw = a.bw;
     const int ncol0 = wcol * 64;
     auto dzp = [&](int l) { return bw + (BW_DZ + (size_t)l * H) * Mp + m0 * H; };
-    auto mskp = [&](int l) { return reinterpret_cast<const xmask_t*>(ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8) + tid; };
+    auto mskp = [&](int l) { return ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8; };
 
     X3Pre<2> pre;
     x3_prefetch<2, HH / 16, ACC_ZERO>(xi + x3::D10, H, ncol0, lane, nullptr, pre);
@@ -689,30 +524,33 @@ __global__ __launch_bounds__(X3_THREADS, 1) void nerf_dgrad_x3_kernel(X3BwdArgs 
     mma_layer_x3<2, HH / 16, ACC_ZERO>(planes, xi + x3::D10, H, ncol0, wrow0, lane, acc, pre);
     x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3::d_img(9), H, ncol0, lane, nullptr, pre);
     __syncthreads();
-    x3_epilogue<4, true>(planes, acc, ncol0, wrow0, lane, bw + BW_DZ9 * Mp + m0 * H, nullptr, 0, nullptr, nullptr);
+    x3_epilogue<4, true>(planes, acc, ncol0, wrow0, lane, bw + BW_DZ9 * Mp + m0 * H, nullptr, nullptr, nullptr);
     __syncthreads();
     // block2.8: feature rows on MFMA + the density row as a rank-1 term, ReLU mask of h8 -> dz8
     {
-        const xmask_t bits = *mskp(8);
+        X3Masks bits;
+        x3_load_masks(mskp(8), ncol0, wrow0, lane, bits);
         mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(9), H, ncol0, wrow0, lane, acc, pre);
         x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3::d_img(8), H, ncol0, lane, nullptr, pre);
         __syncthreads();
-        x3_epilogue<3, true>(planes, acc, ncol0, wrow0, lane, dzp(8), nullptr, bits, dsig_s, pk + SIGW);
+        x3_epilogue<3, true>(planes, acc, ncol0, wrow0, lane, dzp(8), &bits, dsig_s, pk + SIGW);
         __syncthreads();
     }
 #pragma unroll 1
     for (int l = 8; l >= 2; --l) {
-        const xmask_t bits = *mskp(l - 1);
+        X3Masks bits;
+        x3_load_masks(mskp(l - 1), ncol0, wrow0, lane, bits);
         mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(l), H, ncol0, wrow0, lane, acc, pre);
         x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3::d_img(l - 1), H, ncol0, lane, nullptr, pre);
         __syncthreads();
-        x3_epilogue<2, true>(planes, acc, ncol0, wrow0, lane, dzp(l - 1), nullptr, bits, nullptr, nullptr);
+        x3_epilogue<2, true>(planes, acc, ncol0, wrow0, lane, dzp(l - 1), &bits, nullptr, nullptr);
         __syncthreads();
     }
     {
-        const xmask_t bits = *mskp(0);
+        X3Masks bits;
+        x3_load_masks(mskp(0), ncol0, wrow0, lane, bits);
         mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(1), H, ncol0, wrow0, lane, acc, pre);
-        x3_epilogue<2, false>(planes, acc, ncol0, wrow0, lane, dzp(0), nullptr, bits, nullptr, nullptr);
+        x3_epilogue<2, false>(planes, acc, ncol0, wrow0, lane, dzp(0), &bits, nullptr, nullptr);
     }
 }
 
@@ -931,7 +769,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void siren_fwd_x3_kernel(X3FwdArgs a
             ws[WS_SRAW * Mp + m0 + smp] = s;
         }
     }
-    x3_epilogue<0, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_F, H), nullptr, 0, nullptr, nullptr);
+    x3_epilogue<0, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_F, H), nullptr, nullptr, nullptr);
     __syncthreads();
     // rgb sine layer: [f | de] -> 128
     {
@@ -1080,7 +918,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void siren_dgrad_x3_kernel(X3BwdArgs
     mma_layer_x3<2, HH / 16, ACC_ZERO>(planes, xi + x3s::D_RGB, H, ncol0, wrow0, lane, acc, pre);
     x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3s::D_FEAT, H, ncol0, lane, nullptr, pre);
     __syncthreads();
-    x3_epilogue<4, true>(planes, acc, ncol0, wrow0, lane, bw + BW_DZF * Mp + m0 * H, nullptr, 0, nullptr, nullptr);
+    x3_epilogue<4, true>(planes, acc, ncol0, wrow0, lane, bw + BW_DZF * Mp + m0 * H, nullptr, nullptr, nullptr);
     __syncthreads();
     // feature_remap + density branch (rank-1) -> dh7, times cos -> dz7
     load_deriv(7, dv);
@@ -1106,7 +944,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void siren_dgrad_x3_kernel(X3BwdArgs
 }  // namespace
 
 extern "C" size_t nerf_mlp_packed_x3_floats(int model) {
-    return model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS + x3::TOTAL_FLOATS
+    return model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS + x3::TOTAL_FLOATS + nerf_mlp_packed_bf16x3_bytes(model) / 4
          : model == NERF_MODEL_SIREN ? lay::siren::PACKED_FLOATS + x3s::TOTAL_FLOATS : 0;
 }
 
@@ -1122,14 +960,6 @@ extern "C" int nerf_mlp_pack_x3(int model, const float* const* params, float* pa
     a.njobs = 0;
     if (model == NERF_MODEL_NERF) {
         a.dst = reinterpret_cast<__bf16*>(packed + lay::nerf::PACKED_FLOATS);
-        x3_fwd_job(a, 0, PE, 0, H, PE, x3::F_L0, true, true);
-        for (int l = 1; l <= 4; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3::F_L1 + (size_t)(l - 1) * x3::elems(H, H), true, true);
-        x3_fwd_job(a, 10, H + PE, 0, H, H, x3::F_L5A, true, true);
-        x3_fwd_job(a, 10, H + PE, H, H, PE, x3::F_L5B, true, true);
-        for (int l = 6; l <= 8; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3::F_L6 + (size_t)(l - 6) * x3::elems(H, H), true, true);
-        x3_fwd_job(a, 18, H, 0, H, H, x3::F_L9, false, true);
-        x3_fwd_job(a, 20, H + DE, 0, HH, H, x3::F_L10A, true, false);
-        x3_fwd_job(a, 20, H + DE, H, HH, DE, x3::F_L10B, true, false);
         x3_bwd_job(a, 20, H + DE, H, HH, x3::D10);
         x3_bwd_job(a, 18, H, H, H, x3::d_img(9));
         for (int l = 8; l >= 6; --l) x3_bwd_job(a, 2 * l, H, H, H, x3::d_img(l));
@@ -1146,7 +976,10 @@ extern "C" int nerf_mlp_pack_x3(int model, const float* const* params, float* pa
         for (int l = 7; l >= 1; --l) x3_bwd_job(a, 2 * l, H, H, H, x3s::d_img(l));
     }
     pack_x3_kernel<<<dim3(a.njobs, 64), 256, 0, (hipStream_t)stream>>>(a);
-    return nerf_check_launch("nerf_mlp_pack_x3");
+    if ((rc = nerf_check_launch("nerf_mlp_pack_x3"))) return rc;
+    if (model == NERF_MODEL_NERF)   // the forward's ring image
+        return nerf_mlp_pack_bf16x3(model, params, packed + lay::nerf::PACKED_FLOATS + x3::TOTAL_FLOATS, stream);
+    return NERF_OK;
 }
 
 extern "C" int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const float* points, const float* dirs,
@@ -1173,14 +1006,11 @@ extern "C" int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const 
     const size_t fp32_floats = model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS : lay::siren::PACKED_FLOATS;
     X3FwdArgs a{packed, reinterpret_cast<const __bf16*>(packed + fp32_floats), M, mp, points, dirs, rays_o, rays_d,
                 t, S, t_per_ray, (float)near, (float)(far - near), colors, density, workspace};
-    int rc;
-    if (model == NERF_MODEL_NERF) {
-        if ((rc = nerf_set_lds(nerf_fwd_x3_kernel, X3_FWD_LDS_BYTES))) return rc;
-        nerf_fwd_x3_kernel<<<(unsigned)tiles, X3_THREADS, X3_FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
-    } else {
-        if ((rc = nerf_set_lds(siren_fwd_x3_kernel, X3_FWD_LDS_BYTES))) return rc;
-        siren_fwd_x3_kernel<<<(unsigned)tiles, X3_THREADS, X3_FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
-    }
+    if (model == NERF_MODEL_NERF)   // 16-sample tiles, weights through an LDS ring (mlp_x3i.hip)
+        return nerf_x3i_fwd_train(packed + lay::nerf::PACKED_FLOATS + x3::TOTAL_FLOATS, M, points, dirs, rays_o, rays_d, t, S,
+                                  t_per_ray, near, far, colors, density, workspace, stream);
+    if (int rc = nerf_set_lds(siren_fwd_x3_kernel, X3_FWD_LDS_BYTES)) return rc;
+    siren_fwd_x3_kernel<<<(unsigned)tiles, X3_THREADS, X3_FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
     return nerf_check_launch("nerf_mlp_fwd_x3");
 }
 

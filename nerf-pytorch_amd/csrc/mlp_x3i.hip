@@ -45,14 +45,24 @@
 //     flight; the waits for landed pieces removed (still correct: the pieces are never late).
 // Where the cycles go (counters, 1,048,576 samples per launch): the matrix pipe is busy 0.76 of them.  Without the
 // LDS-DMA instructions (stale weights, timing only) the kernel is 12 % faster, without the splits 7 %.
+//
+// Training forward (fwd_x3i_kernel<NeRF, false, TRAIN>, entered through nerf_mlp_fwd_x3): the same kernel also fills the
+// activation workspace of the gradient kernels, every value from the registers that hold it at the end of its layer
+// (16-byte stores, 64 contiguous bytes per sample and tile), and records the ReLU decisions as the sign bits of the
+// negated accumulators.  1,048,576 samples: 5.9 ms against 4.7 ms without the workspace (5.0 ms with the stores alone
+// removed) and 7.45 ms of the 64-sample-tile kernel it replaced, which kept the layer input in LDS planes, had every
+// wave fetch its own weight fragments through the vector cache (twice the L2 traffic per sample) and two workgroup
+// barriers per layer.  Streaming stores (nt) are 3 % slower, a request distance of five chunks changes nothing.
 #include "bf16_common.h"
 
 using namespace bf16k;
 
 namespace {
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int NBUF = 4;
-constexpr int AHEAD = 3;             // a chunk is requested three chunks before it is read
+constexpr int AHEAD = NBUF - 1;      // a chunk is requested three chunks before it is read
 
 constexpr int WAVES = 8;
 constexpr int WG_THREADS = 64 * WAVES;
@@ -82,6 +92,15 @@ struct Geo {
         int t = 0;
         for (int i = 0; i < l; ++i) t += n_ot(i);
         return t;
+    }
+    // Layers followed by a ReLU are stored NEGATED (weights and bias): the accumulators then hold -z, the activation is
+    // max(0, -acc) with the negation in the instruction's source modifier, and the accumulator's sign bit IS the decision
+    // z > 0 that the training forward records for the data gradient (exactly: z = +0 has the bit clear).
+    static constexpr bool negated(int l) { return MODEL == NERF_MODEL_NERF && (l <= 8 || l == 10); }
+    static constexpr unsigned neg_mask() {
+        unsigned m = 0;
+        for (int l = 0; l < NL; ++l) m |= negated(l) ? 1u << l : 0u;
+        return m;
     }
     static constexpr int NCHUNK = chunk0(NL);
     static constexpr int NBIAS_TILES = bias_tile0(NL);
@@ -128,6 +147,7 @@ struct PackArgs {
     LayerInfo layers[NL_MAX];
     int chunk0[NL_MAX + 1];
     int bias_tile0[NL_MAX + 1];
+    unsigned neg_mask;   // bit l: layer l is stored negated
 };
 
 template <int MODEL>
@@ -142,6 +162,7 @@ __global__ __launch_bounds__(256) void pack_x3i_kernel(PackArgs a) {
         const int n_ot = (L.n_out + 15) / 16, nks = L.nks_acc / 2 + enc_ks32(L.enc);
         const int up = (chunk - a.chunk0[l]) * CHUNK_UNITS + unit;
         const int plane = up % 3, u = up / 3;       // the three terms of a fragment are consecutive units
+        const bool neg = (a.neg_mask >> l) & 1u;
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.0f;
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(256) void pack_x3i_kernel(PackArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int col = k_column16(L, ks, q, j);
-                    if (col >= 0) v[j] = bf16_term(w[col], plane);
+                    if (col >= 0) v[j] = bf16_term(neg ? -w[col] : w[col], plane);
                 }
             }
         }
@@ -169,7 +190,7 @@ __global__ __launch_bounds__(256) void pack_x3i_kernel(PackArgs a) {
         const int out = 16 * (tile - a.bias_tile0[l]) + e;
         float b = 0.0f;
         if (out < L.n_out) b = (L.last_row_tensor >= 0 && out == L.n_out - 1) ? a.src[L.last_row_tensor + 1][0] : a.src[L.wtensor + 1][out];
-        reinterpret_cast<float*>(a.dst + G::IMG_BYTES)[p] = b;
+        reinterpret_cast<float*>(a.dst + G::IMG_BYTES)[p] = ((a.neg_mask >> l) & 1u) ? -b : b;
     }
 }
 
@@ -187,6 +208,8 @@ struct FwdArgs {
     float nearf, spanf;
     float* colors;
     float* density;
+    float* ws;    // training forward: the activation workspace (mlp_layout.h), rows of the padded sample count Mp
+    size_t Mp;
 };
 
 struct Ring {
@@ -206,7 +229,7 @@ __device__ __forceinline__ void ring_issue_piece(const Ring& r, int chunk, int i
     if (chunk < r.nchunk) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(r.img), 0, r.img_bytes, 0x00020000);
-        unsigned char* dst = r.lds + (chunk & (NBUF - 1)) * CHUNK_BYTES + PER_CHUNK * 1024 * r.wave;
+        unsigned char* dst = r.lds + (chunk % NBUF) * CHUNK_BYTES + PER_CHUNK * 1024 * r.wave;
         auto lds = (__attribute__((address_space(3))) void*)dst;
         // (the immediate must be a literal for the builtin)
         if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, (int)r.voff, chunk * CHUNK_BYTES, 0, 0);
@@ -220,13 +243,17 @@ __device__ __forceinline__ void ring_issue(const Ring& r, int chunk) {
     for (int i = 0; i < PER_CHUNK; ++i) ring_issue_piece(r, chunk, i);
 }
 
-// publication of the next chunk (header comment).  REM = chunks of the stream that follow the one being read (2 = two
-// or more): with fewer than two, no younger request exists that could stay in flight.
-template <int REM>
+// publication of the next chunk (header comment).  REM = chunks of the stream that follow the one being read: the
+// requests of up to AHEAD - 2 of them, behind the next one, may stay in flight.
+// YOUNGER = vector-memory instructions other than the next-but-one chunk's pieces that were issued after the pieces
+// waited for (the training forward's workspace stores; the counter is shared and retires in issue order): they may stay in
+// flight too.  A value below the true number only waits longer; one above it would publish pieces that have not landed.
+template <int REM, int YOUNGER = 0>
 __device__ __forceinline__ void ring_publish_next() {
     if constexpr (REM >= 1) {
-        if constexpr (REM >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr int IN_FLIGHT = ((REM < AHEAD - 1 ? REM : AHEAD - 1) - 1) * PER_CHUNK;   // requested chunks behind the next one
+        static_assert(IN_FLIGHT + YOUNGER < 64, "vmcnt is a 6-bit field");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT + YOUNGER) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
@@ -269,9 +296,12 @@ __device__ __forceinline__ void init_bias(f32x4 (&acc)[NOT_MAX], const float* bi
 // acc[ot] += W tile (ot, ks) * B(ks) for all ks, consuming the layer's units in image order; k-steps below NKS_A take
 // their B fragment from X, the rest from XE (an encoding).  A fragments are read from LDS PF units ahead of the MFMAs
 // that use them.  Unit 3g+p is term p of fragment g.
-// TAIL = chunks that follow this layer's last chunk in the stream the kernel reads (2 = two or more).
+// TAIL = chunks that follow this layer's last chunk in the stream the kernel reads (AHEAD = that many or more).
 // FIRST_OT: output tiles below it are not computed (their units still pass through the ring).
-template <int NOT, int NKS_A, int NKS_E, int TAIL, int FIRST_OT = 0>
+// NST: workspace stores issued between the previous layer's last unit and this layer's first one.  They are younger
+// than the pieces of this layer's second .. AHEAD-th chunk, whose publications therefore let NST more instructions stay
+// in flight (ring_publish_next).
+template <int NOT, int NKS_A, int NKS_E, int TAIL, int FIRST_OT = 0, int NST = 0>
 __device__ __forceinline__ void mma_layer(Ring& r, int lane, f32x4 (&acc)[NOT_MAX], const u32x4 (&X)[3][8], const u32x4 (&XE)[3][2]) {
     constexpr int CU = CHUNK_UNITS;
     constexpr int NKS = NKS_A + NKS_E, UNITS = 3 * NOT * NKS, CHUNKS = (UNITS + CU - 1) / CU;
@@ -285,13 +315,13 @@ __device__ __forceinline__ void mma_layer(Ring& r, int lane, f32x4 (&acc)[NOT_MA
         constexpr int u = decltype(U)::value;
         if constexpr (u % CU == 0) {
             // one address register per chunk (its offset hidden from the compiler), the units at immediate offsets
-            unsigned off = (unsigned)(r.next & (NBUF - 1)) * CHUNK_BYTES + 16u * (unsigned)lane;
+            unsigned off = (unsigned)(r.next % NBUF) * CHUNK_BYTES + 16u * (unsigned)lane;
             asm volatile("" : "+v"(off));
             ++r.next;
             buf = r.lds + off;
         }
         constexpr int rem = (CHUNKS - 1 - u / CU) + TAIL;
-        if constexpr (u % CU == PUBLISH_AT) ring_publish_next<(rem >= 2 ? 2 : rem)>();
+        if constexpr (u % CU == PUBLISH_AT) ring_publish_next<rem, (u / CU < AHEAD - 1 ? NST : 0)>();
         if constexpr (rem >= 1 && u % CU >= PUBLISH_AT && u % CU < PUBLISH_AT + PER_CHUNK)
             ring_issue_piece(r, r.next - 1 + AHEAD, u % CU - PUBLISH_AT);   // r.next - 1 is the chunk being read
         a[u % PF] = *reinterpret_cast<const u32x4*>(buf + (u % CU) * UNIT_BYTES);
@@ -318,8 +348,15 @@ __device__ __forceinline__ void mma_layer(Ring& r, int lane, f32x4 (&acc)[NOT_MA
 // that with coordinates in [-1, 1]): 8 vector instructions and a table read per value where the polynomial form has
 // 25 -- the epilogues run while no MFMA does, so every one of them is exposed.
 enum FragAct { FR_NONE = 0, FR_RELU = 1, FR_SIN = 2, FR_SIN30 = 3 };
-template <int NPAIR, int ACT>
-__device__ __forceinline__ void to_frags(const f32x4 (&acc)[NOT_MAX], u32x4 (&X)[3][8]) {
+// OUT (training forward): FO_STORE also writes the activated tiles as fp32 to the workspace rows of this workgroup (rsrc;
+// voff = this lane's row and its 16-byte column group; tile ot at byte 64 ot of the row: 16 bytes per lane and tile, 64
+// contiguous bytes per sample); FO_MASK also collects the decisions z > 0 of a ReLU layer in mw: tile ot, register g at bit
+// 31 - (4 (ot & 7) + g) of mw[ot >> 3].
+enum FragOut { FO_NONE = 0, FO_STORE = 1, FO_MASK = 2 };
+template <int NPAIR, int ACT, int OUT>
+__device__ __forceinline__ void to_frags_out(const f32x4 (&acc)[NOT_MAX], u32x4 (&X)[3][8], __amdgpu_buffer_rsrc_t rsrc, int voff,
+                                             unsigned (&mw)[2]) {
+    static_assert(OUT != FO_MASK || ACT == FR_RELU, "mask bits are the signs of negated ReLU pre-activations");
 #pragma unroll
     for (int s = 0; s < NPAIR; ++s) {
         f32x2 v[4];
@@ -336,19 +373,40 @@ __device__ __forceinline__ void to_frags(const f32x4 (&acc)[NOT_MAX], u32x4 (&X)
                 dev::sincos_tab_finish(pr[jp], v[jp], cs);
             }
         }
+        float h[8];
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
             float v0 = v[jp][0], v1 = v[jp][1];
-            if constexpr (ACT == FR_RELU) {   // (fmaxf puts a canonicalising v_max v, v, v in front of the v_max)
-                asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
-                asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+            if constexpr (ACT == FR_RELU) {
+                if constexpr (OUT == FO_MASK) {
+                    mw[s >> 2] = __builtin_amdgcn_alignbit(mw[s >> 2], __builtin_bit_cast(unsigned, v0), 31);
+                    mw[s >> 2] = __builtin_amdgcn_alignbit(mw[s >> 2], __builtin_bit_cast(unsigned, v1), 31);
+                }
+                // the layer's image is negated (Geo::negated): relu(z) = max(0, -acc)
+                asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v0) : "v"(v0));
+                asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v1) : "v"(v1));
             }
+            h[2 * jp] = v0;
+            h[2 * jp + 1] = v1;
             unsigned tm[3];
             split2<3>(v0, v1, tm);
 #pragma unroll
             for (int p = 0; p < 3; ++p) X[p][s][jp] = tm[p];
         }
+        if constexpr (OUT != FO_NONE) {
+            // constant scalar offset 0: with it the compiler keeps the next writer of the data registers one slot away
+            // (a store of this width reads them a cycle late); the tile's place in the row becomes the immediate offset
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{h[4 * t], h[4 * t + 1], h[4 * t + 2], h[4 * t + 3]}),
+                                                       rsrc, voff + (2 * s + t) * 64, 0, 0);
+        }
     }
+}
+template <int NPAIR, int ACT>
+__device__ __forceinline__ void to_frags(const f32x4 (&acc)[NOT_MAX], u32x4 (&X)[3][8]) {
+    unsigned none[2] = {0u, 0u};
+    to_frags_out<NPAIR, ACT, FO_NONE>(acc, X, __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0), 0, none);
 }
 
 template <int N, int NKS>
@@ -371,8 +429,14 @@ __device__ __forceinline__ void vals_to_frags(const float (&v)[N], u32x4 (&X)[3]
 
 // DENSITY_ONLY (colors == NULL): the stream ends with the layer that holds the density row -- the coarse pass of a
 // hierarchical render without gradients feeds only the re-sampling.
-template <int MODEL, bool DENSITY_ONLY>
+// TRAIN (NeRF model): also fills the activation workspace that the data-gradient and weight-gradient kernels of the
+// bf16x3 training mode read (pe, de, h0..h8, f, g, the density pre-activation, the ReLU decisions of h0..h8), every
+// value straight from the registers that hold it.  ReLU decisions: one 8-byte word per lane and layer -- sample c of the
+// wave's 16, lane group q: bit 31 - (4 (ot & 7) + g) of word ot >> 3 is the decision of feature 16 ot + 4 q + g -- at
+// byte 32 m + 8 q of the layer's mask field (32 bytes per sample m).
+template <int MODEL, bool DENSITY_ONLY, bool TRAIN = false>
 __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
+    static_assert(!TRAIN || (MODEL == NERF_MODEL_NERF && !DENSITY_ONLY), "training forward: NeRF model, all outputs");
     using G = Geo<MODEL>;
     constexpr auto bias_tile0 = [](int l) { return G::bias_tile0(l); };
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -413,11 +477,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing ordinary is outstanding from here on
     __builtin_amdgcn_sched_barrier(0);
+    // workspace rows of this workgroup: a field of `width` floats per sample as a buffer resource that ends with the
+    // padded sample count (stores to rows behind it are dropped by the bounds check), this lane's row in row_local
+    const size_t m0g = (size_t)blockIdx.x * WG_SAMPLES;
+    const int row_local = wave * 16 + (lane & 15);
+    [[maybe_unused]] const auto field = [&](size_t off, int width) {
+        const size_t rows = a.Mp - m0g < (size_t)WG_SAMPLES ? a.Mp - m0g : (size_t)WG_SAMPLES;
+        return __builtin_amdgcn_make_buffer_rsrc(a.ws + off * a.Mp + m0g * width, 0, (int)rows * width * 4, 0x00020000);
+    };
+    [[maybe_unused]] const auto put = [](float v, __amdgpu_buffer_rsrc_t rsrc, int voff) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff, 0, 0);
+    };
     constexpr int DENSITY_LAYER = MODEL == NERF_MODEL_NERF ? 9 : 8;
     // chunks of the stream this variant reads (nothing may be in flight towards LDS when the workgroup ends)
     constexpr int NCHUNK_RUN = DENSITY_ONLY ? G::chunk0(DENSITY_LAYER + 1) : G::NCHUNK;
     // chunks behind layer l's last one, as mma_layer's TAIL
-    constexpr auto tail = [](int l) { return NCHUNK_RUN - G::chunk0(l + 1) < 2 ? NCHUNK_RUN - G::chunk0(l + 1) : 2; };
+    constexpr auto tail = [](int l) { return NCHUNK_RUN - G::chunk0(l + 1) < AHEAD ? NCHUNK_RUN - G::chunk0(l + 1) : AHEAD; };
     Ring ring{a.img, ring_lds, 0, (unsigned)(PER_CHUNK * 1024 * wave + 16 * lane), wave, NCHUNK_RUN, (int)G::IMG_BYTES};
 #pragma unroll
     for (int c = 0; c < AHEAD; ++c) ring_issue(ring, c);   // these land while the encodings below are computed
@@ -442,6 +517,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
         }
         v[15] = q == 0 ? x[0] : q == 1 ? x[1] : q == 2 ? x[2] : 0.0f;
         vals_to_frags<16, 2>(v, E0);
+        if constexpr (TRAIN) {
+            // pe in the column order of nerf/encoding.py:14-18 (x, then sin xyz, cos xyz per frequency), column 63 zero
+            const __amdgpu_buffer_rsrc_t pe = field(lay::nerf::WS_PE, lay::PE_P);
+            const int row = row_local * lay::PE_P * 4;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) put(v[e], pe, row + 48 * q + (3 + e) * 4);                       // frequencies 2q, 2q+1
+#pragma unroll
+            for (int c = 0; c < 3; ++c) put(v[12 + c], pe, row + (51 + 6 * (q >> 1) + 3 * (q & 1)) * 4 + c * 4);   // 8 + q/2
+            put(v[15], pe, row + (q < 3 ? q : 63) * 4);
+        }
     } else {
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -465,28 +550,48 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
         v[6] = q == 0 ? d[0] : q == 1 ? d[1] : q == 2 ? d[2] : 0.0f;
         v[7] = 0.0f;
         vals_to_frags<8, 2>(v, DE);
+        if constexpr (TRAIN) {
+            // de in the reference's column order; columns 27..31 (padding of the 32-wide field) zero
+            const __amdgpu_buffer_rsrc_t de = field(lay::nerf::WS_DE, lay::DE_P);
+            const int row = row_local * lay::DE_P * 4;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) put(v[e], de, row + 24 * q + (3 + e) * 4);
+            put(v[6], de, row + (q < 3 ? q : 27) * 4);
+            put(0.0f, de, row + (28 + q) * 4);
+        }
+    };
+    constexpr int N_PE_STORES = TRAIN ? 16 : 0, N_DE_STORES = TRAIN ? 8 : 0, N_H_STORES = TRAIN ? 17 : 0;
+    // a 256-wide ReLU layer's epilogue: fragments of the next layer, and in training the layer's workspace row and masks
+    [[maybe_unused]] const auto relu_layer_out = [&](int l) {
+        if constexpr (TRAIN) {
+            unsigned mw[2] = {0u, 0u};
+            to_frags_out<8, FR_RELU, FO_MASK>(acc, X, field(lay::nerf::WS_H + (size_t)l * lay::H, lay::H), row_local * lay::H * 4 + q * 16, mw);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{mw[0], mw[1]}, field(lay::nerf::WS_MASK + 8 * (size_t)l, 8), row_local * 32 + q * 8, 0, 0);
+        } else {
+            to_frags<8, FR_RELU>(acc, X);
+        }
     };
     float dens;
 
     if constexpr (MODEL == NERF_MODEL_NERF) {
         init_bias<16>(acc, bias_lds, bias_tile0(0), q);
-        mma_layer<16, 0, 2, tail(0)>(ring, lane, acc, X, E0);
-        to_frags<8, FR_RELU>(acc, X);
+        mma_layer<16, 0, 2, tail(0), 0, N_PE_STORES>(ring, lane, acc, X, E0);
+        relu_layer_out(0);
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
             init_bias<16>(acc, bias_lds, 16 * l, q);
-            mma_layer<16, 8, 0, tail(4)>(ring, lane, acc, X, E0);
-            to_frags<8, FR_RELU>(acc, X);
+            mma_layer<16, 8, 0, tail(4), 0, N_H_STORES>(ring, lane, acc, X, E0);
+            relu_layer_out(l);
         }
         // skip layer: [features | position encoding]
         init_bias<16>(acc, bias_lds, bias_tile0(5), q);
-        mma_layer<16, 8, 2, tail(5)>(ring, lane, acc, X, E0);
-        to_frags<8, FR_RELU>(acc, X);
+        mma_layer<16, 8, 2, tail(5), 0, N_H_STORES>(ring, lane, acc, X, E0);
+        relu_layer_out(5);
 #pragma unroll 1
         for (int l = 6; l <= 8; ++l) {
             init_bias<16>(acc, bias_lds, 16 * l, q);
-            mma_layer<16, 8, 0, tail(8)>(ring, lane, acc, X, E0);
-            to_frags<8, FR_RELU>(acc, X);
+            mma_layer<16, 8, 0, tail(8), 0, N_H_STORES>(ring, lane, acc, X, E0);
+            relu_layer_out(l);
         }
         // block2.8: 256 feature rows (no activation) + the density row (first row of the 17th tile)
         init_bias<17>(acc, bias_lds, bias_tile0(9), q);
@@ -495,15 +600,26 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
             if (valid && q == 0) a.density[m] = fmaxf(acc[16][0], 0.0f);
             return;
         }
-        mma_layer<17, 8, 0, tail(9)>(ring, lane, acc, X, E0);
+        mma_layer<17, 8, 0, tail(9), 0, N_H_STORES>(ring, lane, acc, X, E0);
         dens = fmaxf(acc[16][0], 0.0f);
-        to_frags<8, FR_NONE>(acc, X);
+        if constexpr (TRAIN) {
+            if (q == 0) put(acc[16][0], field(lay::nerf::WS_SRAW, 1), row_local * 4);
+            unsigned none[2];
+            to_frags_out<8, FR_NONE, FO_STORE>(acc, X, field(lay::nerf::WS_F, lay::H), row_local * lay::H * 4 + q * 16, none);
+        } else {
+            to_frags<8, FR_NONE>(acc, X);
+        }
         // rgb head: [features | direction encoding] -> 128, ReLU
         u32x4 DE[3][2];
         direction_frags(DE);
         init_bias<8>(acc, bias_lds, bias_tile0(10), q);
-        mma_layer<8, 8, 1, tail(10)>(ring, lane, acc, X, DE);
-        to_frags<4, FR_RELU>(acc, X);
+        mma_layer<8, 8, 1, tail(10), 0, (TRAIN ? 17 + N_DE_STORES : 0)>(ring, lane, acc, X, DE);
+        if constexpr (TRAIN) {
+            unsigned none[2];
+            to_frags_out<4, FR_RELU, FO_STORE>(acc, X, field(lay::nerf::WS_G, lay::HH), row_local * lay::HH * 4 + q * 16, none);
+        } else {
+            to_frags<4, FR_RELU>(acc, X);
+        }
         init_bias<1>(acc, bias_lds, bias_tile0(11), q);
         mma_layer<1, 4, 0, 0>(ring, lane, acc, X, DE);
     } else {
@@ -557,6 +673,7 @@ int pack_image(const float* const* params, void* packed, void* stream, const cha
         a.chunk0[l] = G::chunk0(l < G::NL ? l : G::NL);
         a.bias_tile0[l] = G::bias_tile0(l < G::NL ? l : G::NL);
     }
+    a.neg_mask = G::neg_mask();
     const int pieces = G::NCHUNK * CHUNK_UNITS * 64;
     pack_x3i_kernel<MODEL><<<(pieces + 255) / 256, 256, 0, (hipStream_t)stream>>>(a);
     return nerf_check_launch(who);
@@ -577,6 +694,22 @@ int launch_fwd(const FwdArgs& a, int64_t M, void* stream, const char* who) {
 }
 
 }  // namespace
+
+// Training forward of the bf16x3 mode (NeRF model), called by nerf_mlp_fwd_x3 with arguments it has checked: `image` is
+// what nerf_mlp_pack_bf16x3 wrote, `workspace` the activation workspace of nerf_mlp_fwd_workspace_floats.
+__attribute__((visibility("hidden"))) int nerf_x3i_fwd_train(const void* image, int64_t M, const float* points, const float* dirs,
+                                                             const float* rays_o, const float* rays_d, const float* t, int S,
+                                                             int t_per_ray, double near, double far, float* colors, float* density,
+                                                             float* workspace, void* stream) {
+    const char* who = "nerf_mlp_fwd_x3";
+    const int64_t groups = ceil_div64(M, WG_SAMPLES);
+    if (groups >= (1ll << 31)) return nerf_fail(NERF_E_ARG, "%s: too many samples", who);
+    FwdArgs a{static_cast<const unsigned char*>(image), M, points, dirs, rays_o, rays_d, t, S, t_per_ray,
+              (float)near, (float)(far - near), colors, density, workspace, lay::padded_samples(M)};
+    if (int rc = nerf_set_lds(fwd_x3i_kernel<NERF_MODEL_NERF, false, true>, LDS_BYTES)) return rc;
+    fwd_x3i_kernel<NERF_MODEL_NERF, false, true><<<(unsigned)groups, WG_THREADS, LDS_BYTES, (hipStream_t)stream>>>(a);
+    return nerf_check_launch(who);
+}
 
 extern "C" size_t nerf_mlp_packed_bf16x3_bytes(int model) {
     return model == NERF_MODEL_NERF ? Geo<NERF_MODEL_NERF>::PACKED_BYTES : model == NERF_MODEL_SIREN ? Geo<NERF_MODEL_SIREN>::PACKED_BYTES : 0;
@@ -606,6 +739,6 @@ extern "C" int nerf_mlp_fwd_bf16x3(int model, const void* packed, int64_t M, con
         if (far == near) return nerf_fail(NERF_E_ARG, "%s: near == far", who);
     }
     FwdArgs a{static_cast<const unsigned char*>(packed), M, points, dirs, rays_o, rays_d, t, S, t_per_ray,
-              (float)near, (float)(far - near), colors, density};
+              (float)near, (float)(far - near), colors, density, nullptr, 0};
     return model == NERF_MODEL_SIREN ? launch_fwd<NERF_MODEL_SIREN>(a, M, stream, who) : launch_fwd<NERF_MODEL_NERF>(a, M, stream, who);
 }

@@ -272,7 +272,7 @@ def mlp_pack(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Ten
 
 def mlp_pack_x3(model: int, params: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Weight image of the opt-in bf16x3 TRAINING mode: the fp32 image of mlp_pack followed by the three-term bf16
-    planes of every dense layer, forward and transposed.  mlp_fwd / mlp_bwd recognise it by its size; a pass without a
+    images of every dense layer that the mode's forward and data-gradient kernels stream.  mlp_fwd / mlp_bwd recognise it by its size; a pass without a
     workspace (inference) reads the fp32 part alone."""
     if len(params) != NUM_PARAM_TENSORS:
         raise ValueError(f"expected {NUM_PARAM_TENSORS} parameter tensors, got {len(params)}")

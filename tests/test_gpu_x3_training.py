@@ -148,3 +148,44 @@ def test_bf16x3_mode_is_switchable():
         outs.append((c.detach().clone(), m.block1[0].weight.grad.clone()))
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])   # back on the fp32 kernels, bit for bit
     assert rel(outs[1][0], outs[0][0]) < RTOL
+
+
+@pytest.mark.parametrize("M", [1, 100, 129, 1000, 4133])
+def test_bf16x3_forward_fills_the_workspace_of_the_fp32_forward(M):
+    """NeRF model: the bf16x3 training forward (16-sample tiles, 128 samples per workgroup) writes every workspace field the
+    gradient kernels read where the fp32 forward writes it (pe, de, h0..h8, f, g, density pre-activation; rows up to the
+    padded sample count, which need not be a multiple of 128), to 1e-5; its ReLU decisions, in its own layout (32 bytes
+    per sample: word 2q + (ot >> 3), bit 31 - (4 (ot & 7) + g) = feature 16 ot + 4 q + g), are exactly h > 0."""
+    from nerf import _hip
+    model, _ = make_model("nerf")
+    g = torch.Generator().manual_seed(M)
+    pts = (torch.rand(M, 3, generator=g) * 2 - 1).to(DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=1).to(DEV)
+    c32, d32, ws32 = _hip.mlp_fwd(model.model_id, model.packed_weights(True), M, points=pts, dirs=dirs, train=True)
+    model.set_training_precision("bf16x3")
+    c3, d3, ws3 = _hip.mlp_fwd(model.model_id, model.packed_weights(True), M, points=pts, dirs=dirs, train=True)
+    assert _hip.is_x3_image(model.model_id, model.packed_weights(True))
+    assert rel(c3, c32) < RTOL and rel(d3, d32) < RTOL
+    Mp = -(-M // 64) * 64
+    assert ws3.numel() == ws32.numel() == Mp * (64 + 32 + 9 * 256 + 256 + 128 + 1 + 72)
+    fields = [("pe", 0, 64), ("de", 64, 32)] + [(f"h{l}", 96 + 256 * l, 256) for l in range(9)]
+    fields += [("f", 96 + 9 * 256, 256), ("g", 96 + 10 * 256, 128), ("sraw", 96 + 10 * 256 + 128, 1)]
+    for name, off, width in fields:
+        a = ws3[off * Mp:(off + width) * Mp].view(Mp, width)
+        b = ws32[off * Mp:(off + width) * Mp].view(Mp, width)
+        assert rel(a[:M], b[:M]) < RTOL, name
+        scale = float(b[:M].abs().max())
+        assert float((a[:M] - b[:M]).abs().max()) <= 2e-5 * max(scale, 1.0), name
+        assert torch.isfinite(a).all(), name                      # rows M..Mp are written too (zero inputs)
+    assert float(ws3[:64 * Mp].view(Mp, 64)[:, 63].abs().max()) == 0.0                               # padding columns
+    de = ws3[64 * Mp:96 * Mp].view(Mp, 32)
+    assert float(de[:, 27:].abs().max()) == 0.0
+    mask0 = 96 + 10 * 256 + 128 + 1
+    feat = torch.arange(256, device=DEV)
+    ot, q, gg = feat // 16, (feat % 16) // 4, feat % 4
+    word, bit = 2 * q + ot // 8, 31 - (4 * (ot % 8) + gg)
+    for l in range(9):
+        words = ws3[(mask0 + 8 * l) * Mp:(mask0 + 8 * l + 8) * Mp].view(torch.int32).view(Mp, 8)
+        decided = (words[:, word] >> bit) & 1                                      # [Mp, 256]
+        h = ws3[(96 + 256 * l) * Mp:(96 + 256 * (l + 1)) * Mp].view(Mp, 256)
+        assert torch.equal(decided.bool(), h > 0), f"mask of h{l}"
