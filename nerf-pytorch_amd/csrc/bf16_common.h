@@ -27,6 +27,11 @@ struct LayerInfo {
     int ld;        // row pitch of the [out, in] weight tensor
     int wtensor;   // state_dict index of the weight; the bias follows it
     int last_row_tensor;   // >= 0: output row n_out-1 is row 0 of this [1, ld] weight (its bias follows it)
+    // Layers of a data-gradient chain (mlp_x3i.hip): the layer computes dX = dZ W, its A operand is W transposed --
+    // "output row" i is input column i of the [n_in, ld] weight, k runs over the weight's rows.  rank1_tensor >= 0: the
+    // layer's bias image holds row rank1_row of that tensor (the density row, whose gradient enters as a rank-1 term).
+    int transposed;
+    int rank1_tensor, rank1_row;
 };
 constexpr int NL_MAX = 12;
 template <int MODEL> struct Net;

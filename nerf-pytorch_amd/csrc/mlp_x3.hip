@@ -32,7 +32,11 @@
 
 using namespace dev;
 
-// mlp_x3i.hip
+// mlp_x3i.hip: the NeRF model's kernels of this mode
+size_t nerf_x3i_dgrad_image_bytes();
+int nerf_x3i_dgrad_pack(const float* const* params, void* image, void* stream);
+int nerf_x3i_dgrad(const void* image, const float* w11, int64_t M, const float* dcolors, const float* ddensity, const float* colors,
+                   const float* fwd_workspace, float* bwd_workspace, void* stream);
 int nerf_x3i_fwd_train(const void* image, int64_t M, const float* points, const float* dirs, const float* rays_o,
                        const float* rays_d, const float* t, int S, int t_per_ray, double near, double far, float* colors,
                        float* density, float* workspace, void* stream);
@@ -62,17 +66,6 @@ static_assert(TR * LDG * 4 <= PLANES_BYTES, "fp32 view of the plane area");
 // One dense layer, K padded to 16: three planes of [K/16][N][16] bf16; element (ks, pos, h, j) of a plane is term p of
 // W[col(pos)][16 ks + 8 h + j].  col(pos) = pos for the 128-wide layer; for 256-wide outputs the two 32-column tiles
 // of a wave interleave: position 64 w + 32 ni + r holds column 64 w + 2 r + ni.
-namespace x3 {
-using namespace lay;
-constexpr size_t elems(int Kp, int N) { return (size_t)3 * Kp * N; }
-constexpr size_t D10 = 0;   // the data-gradient chain's images; the forward streams the ring image of mlp_x3i.hip, which follows them
-constexpr size_t D9 = D10 + elems(HH, H);
-constexpr size_t TOTAL = D9 + 9 * elems(H, H);
-constexpr size_t d_img(int layer) { return D9 + (size_t)(9 - layer) * elems(H, H); }   // layer 1..9
-static_assert(TOTAL % 8 == 0 && lay::nerf::PACKED_FLOATS % 4 == 0, "16-byte pieces");
-constexpr size_t TOTAL_FLOATS = TOTAL / 2;
-}  // namespace x3
-
 struct X3Job {
     int tensor, src_off, sn, sk;   // W element (n, k) = src[tensor][src_off + n*sn + k*sk]
     int N, K, Kp;
@@ -245,80 +238,33 @@ __device__ __forceinline__ void store_value(unsigned char* planes, int row, int 
         *reinterpret_cast<unsigned short*>(planes + p * PLANE_BYTES + row * LDPB + col * 2) = (unsigned short)w[p];
 }
 
-// ReLU decisions (z > 0) of one 256-wide layer for a lane's 32 accumulator elements, as the forward kernel stores them
-// (mlp_x3i.hip: 32 bytes per sample; word 2 q + (ot >> 3) of a sample holds feature 16 ot + 4 q + g at bit
-// 31 - (4 (ot & 7) + g)).  A lane owns two adjacent columns of 16 rows: one word per row, and in every word the same two
-// neighbouring bits, which `shift` moves to bits 31 and 30.
-struct X3Masks {
-    unsigned w[16];   // row of accumulator register g (both tiles)
-    int shift;
-};
-// field: the layer's mask field at this tile's first sample
-__device__ __forceinline__ void x3_load_masks(const float* field, int ncol0, int wrow0, int lane, X3Masks& m) {
-    const int r = lane & 31, h = lane >> 5;
-    const int f0 = ncol0 + 2 * r;                         // the lane's first column; f0 + 1 is in the same word
-    const int word = ((f0 >> 2) & 3) * 2 + (f0 >> 7);
-    m.shift = 4 * ((f0 >> 4) & 7) + (f0 & 3);
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(field, (unsigned)(TR * 32));
-    const int voff = (wrow0 + 4 * h) * 32 + word * 4;
-#pragma unroll
-    for (int g = 0; g < 16; ++g)
-        m.w[g] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + ((g & 3) + 8 * (g >> 2)) * 32, 0, 0);
-}
-
 // Epilogue of a 256-wide layer (two interleaved tiles per wave): the fp32 tile to the workspace, the three terms to the
 // planes.
-//   MODE 0: forward, no activation
-//   MODE 2: backward, mask in               MODE 3: backward, rank-1 term (dsig[row] * sigw[col]) then mask in
-//   MODE 4: backward, nothing
+//   MODE 0: forward, no activation          MODE 4: backward, nothing
 // gout: this tile's [64][256] fp32 rows in the workspace (NULL: not stored).  TO_PLANES false: the last layer of a chain.
 template <int MODE, bool TO_PLANES>
 __device__ __forceinline__ void x3_epilogue(unsigned char* planes, f32x16 (&acc)[2], int ncol0, int wrow0, int lane,
-                                            float* __restrict__ gout, const X3Masks* mask_in,
-                                            const float* dsig_lds, const float* __restrict__ sigw) {
+                                            float* __restrict__ gout) {
     const int r = lane & 31, h = lane >> 5;
     const int col = ncol0 + 2 * r;
     const __amdgpu_buffer_rsrc_t g_rsrc = make_rsrc(gout, (unsigned)(TR * lay::H * 4));
     const int g_voff = ((wrow0 + 4 * h) * lay::H + col) * 4;
     unsigned char* pl = planes + (wrow0 + 4 * h) * LDPB + col * 2;
-    f32x2 sw = {0.f, 0.f};
-    if constexpr (MODE == 3) sw = *reinterpret_cast<const f32x2*>(sigw + col);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const int row0 = (g & 3) + 8 * (g >> 2);      // + wrow0 + 4 h
-        float v[2] = {acc[0][g], acc[1][g]};
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            if constexpr (MODE == 3) v[ni] = fmaf(dsig_lds[wrow0 + row0 + 4 * h], sw[ni], v[ni]);
-            if constexpr (MODE == 2 || MODE == 3) {
-                // row g's word, this lane's column pair moved to bits 31 and 30: 0 or all ones
-                const int w = (int)(mask_in->w[g] << mask_in->shift);
-                const int keep = ni == 0 ? (w >> 31) : __builtin_amdgcn_sbfe(w, 30, 1);
-                v[ni] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[ni]) & keep);
-            }
-        }
-#ifdef X3_EXP_NOSTORE
-        if (false) {
-#else
+        const float v[2] = {acc[0][g], acc[1][g]};
         if (gout) {
-#endif
             // 8 bytes per lane, 256 contiguous bytes per row and store (a 64-bit store is exempt from the wide-store
             // data hazard that keeps the 16-byte stores of the fp32 kernels on immediate offsets)
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, (f32x2){v[0], v[1]}), g_rsrc, g_voff,
                                                   row0 * lay::H * 4, 2);
         }
-#ifdef X3_EXP_NOSPLIT
-        if constexpr (TO_PLANES) {
-            unsigned w[3] = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), 0u};
-            store_terms(pl, row0 * LDPB, w);
-        }
-#else
         if constexpr (TO_PLANES) {
             unsigned w[3];
             split2(v[0], v[1], w);
             store_terms(pl, row0 * LDPB, w);
         }
-#endif
     }
 }
 
@@ -451,108 +397,6 @@ struct X3BwdArgs {
     const float* ws;
     float* bw;
 };
-
-__global__ __launch_bounds__(X3_THREADS, 1) void nerf_dgrad_x3_kernel(X3BwdArgs a) {
-    using namespace lay;
-    using namespace lay::nerf;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
-    unsigned char* planes = smem_x3;
-    float* dsig_s = reinterpret_cast<float*>(planes + PLANES_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wrow0 = (wave >> 2) * 32, wcol = wave & 3;
-    const size_t m0 = (size_t)blockIdx.x * TR;
-    const size_t Mp = a.Mp;
-    const float* __restrict__ pk = a.pk;
-    const __bf16* __restrict__ xi = a.x3;
-    const float* ws = a.ws;
-    float* bw = a.bw;
-    const int ncol0 = wcol * 64;
-    auto dzp = [&](int l) { return bw + (BW_DZ + (size_t)l * H) * Mp + m0 * H; };
-    auto mskp = [&](int l) { return ws + (WS_MASK + 8 * (size_t)l) * Mp + m0 * 8; };
-
-    X3Pre<2> pre;
-    x3_prefetch<2, HH / 16, ACC_ZERO>(xi + x3::D10, H, ncol0, lane, nullptr, pre);
-    // gradient of the 128 -> 3 sigmoid head (head_bwd of mlp_bwd.hip), its result dz10 [64][128] into the planes
-    if (tid < 256) {
-        const int smp = tid / TPS, q = tid % TPS;
-        const size_t m = m0 + smp;
-        float dz[3] = {0.f, 0.f, 0.f};
-        float ds = 0.f;
-        if (m < (size_t)a.M) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float col = a.colors[m * 3 + c];
-                dz[c] = a.dcolors[m * 3 + c] * col * (1.0f - col);
-            }
-            ds = ws[WS_SRAW * Mp + m] > 0.0f ? a.ddensity[m] : 0.0f;
-        }
-        if (q == 0) {
-            f32x4 v = {dz[0], dz[1], dz[2], 0.0f};
-            *reinterpret_cast<f32x4*>(bw + BW_DZ11 * Mp + m * 4) = v;
-            bw[BW_DSIG * Mp + m] = ds;
-            dsig_s[smp] = ds;
-        }
-        const float* wout = pk + W11;
-        const float* gsrc = ws + WS_G * Mp;
-        float* bw_dzr = bw + BW_DZ10 * Mp;
-#pragma unroll
-        for (int i = 0; i < 32 / TPS; ++i) {
-            const int k = 4 * (TPS * i + q);
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wout + k);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wout + HH + k);
-            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wout + 2 * HH + k);
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(gsrc + m * HH + k);
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = dz[0] * w0[e] + dz[1] * w1[e] + dz[2] * w2[e];
-                v[e] = gv[e] > 0.0f ? d : 0.0f;
-            }
-            *reinterpret_cast<f32x4*>(bw_dzr + m * HH + k) = v;
-            unsigned wa[3], wb[3];
-            split2(v[0], v[1], wa);
-            split2(v[2], v[3], wb);
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                *reinterpret_cast<u32x2_t*>(planes + p * PLANE_BYTES + smp * LDPB + k * 2) = u32x2_t{wa[p], wb[p]};
-        }
-    }
-    __syncthreads();
-    f32x16 acc[2];
-    // rgb_head.0 (feature part): reduce over its 128 outputs -> dz9, the gradient of the 256 features
-    mma_layer_x3<2, HH / 16, ACC_ZERO>(planes, xi + x3::D10, H, ncol0, wrow0, lane, acc, pre);
-    x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3::d_img(9), H, ncol0, lane, nullptr, pre);
-    __syncthreads();
-    x3_epilogue<4, true>(planes, acc, ncol0, wrow0, lane, bw + BW_DZ9 * Mp + m0 * H, nullptr, nullptr, nullptr);
-    __syncthreads();
-    // block2.8: feature rows on MFMA + the density row as a rank-1 term, ReLU mask of h8 -> dz8
-    {
-        X3Masks bits;
-        x3_load_masks(mskp(8), ncol0, wrow0, lane, bits);
-        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(9), H, ncol0, wrow0, lane, acc, pre);
-        x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3::d_img(8), H, ncol0, lane, nullptr, pre);
-        __syncthreads();
-        x3_epilogue<3, true>(planes, acc, ncol0, wrow0, lane, dzp(8), &bits, dsig_s, pk + SIGW);
-        __syncthreads();
-    }
-#pragma unroll 1
-    for (int l = 8; l >= 2; --l) {
-        X3Masks bits;
-        x3_load_masks(mskp(l - 1), ncol0, wrow0, lane, bits);
-        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(l), H, ncol0, wrow0, lane, acc, pre);
-        x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3::d_img(l - 1), H, ncol0, lane, nullptr, pre);
-        __syncthreads();
-        x3_epilogue<2, true>(planes, acc, ncol0, wrow0, lane, dzp(l - 1), &bits, nullptr, nullptr);
-        __syncthreads();
-    }
-    {
-        X3Masks bits;
-        x3_load_masks(mskp(0), ncol0, wrow0, lane, bits);
-        mma_layer_x3<2, H / 16, ACC_ZERO>(planes, xi + x3::d_img(1), H, ncol0, wrow0, lane, acc, pre);
-        x3_epilogue<2, false>(planes, acc, ncol0, wrow0, lane, dzp(0), &bits, nullptr, nullptr);
-    }
-}
 
 
 // =====================================================================================================================
@@ -769,7 +613,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void siren_fwd_x3_kernel(X3FwdArgs a
             ws[WS_SRAW * Mp + m0 + smp] = s;
         }
     }
-    x3_epilogue<0, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_F, H), nullptr, nullptr, nullptr);
+    x3_epilogue<0, true>(planes, acc, ncol0, wrow0, lane, wsp(WS_F, H));
     __syncthreads();
     // rgb sine layer: [f | de] -> 128
     {
@@ -918,7 +762,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void siren_dgrad_x3_kernel(X3BwdArgs
     mma_layer_x3<2, HH / 16, ACC_ZERO>(planes, xi + x3s::D_RGB, H, ncol0, wrow0, lane, acc, pre);
     x3_prefetch<2, H / 16, ACC_ZERO>(xi + x3s::D_FEAT, H, ncol0, lane, nullptr, pre);
     __syncthreads();
-    x3_epilogue<4, true>(planes, acc, ncol0, wrow0, lane, bw + BW_DZF * Mp + m0 * H, nullptr, nullptr, nullptr);
+    x3_epilogue<4, true>(planes, acc, ncol0, wrow0, lane, bw + BW_DZF * Mp + m0 * H);
     __syncthreads();
     // feature_remap + density branch (rank-1) -> dh7, times cos -> dz7
     load_deriv(7, dv);
@@ -944,7 +788,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void siren_dgrad_x3_kernel(X3BwdArgs
 }  // namespace
 
 extern "C" size_t nerf_mlp_packed_x3_floats(int model) {
-    return model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS + x3::TOTAL_FLOATS + nerf_mlp_packed_bf16x3_bytes(model) / 4
+    return model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS + (nerf_mlp_packed_bf16x3_bytes(model) + nerf_x3i_dgrad_image_bytes()) / 4
          : model == NERF_MODEL_SIREN ? lay::siren::PACKED_FLOATS + x3s::TOTAL_FLOATS : 0;
 }
 
@@ -955,31 +799,25 @@ extern "C" int nerf_mlp_pack_x3(int model, const float* const* params, float* pa
     int rc = nerf_mlp_pack(model, params, packed, stream);   // the fp32 image comes first (thin vectors, biases, inference)
     if (rc) return rc;
     using namespace lay;
+    if (model == NERF_MODEL_NERF) {
+        // both chains run on the ring kernels of mlp_x3i.hip: the forward's image, then the data-gradient chain's
+        float* fwd_img = packed + lay::nerf::PACKED_FLOATS;
+        if ((rc = nerf_mlp_pack_bf16x3(model, params, fwd_img, stream))) return rc;
+        return nerf_x3i_dgrad_pack(params, fwd_img + nerf_mlp_packed_bf16x3_bytes(model) / 4, stream);
+    }
     X3PackArgs a;
     for (int i = 0; i < NERF_NUM_PARAM_TENSORS; ++i) a.src[i] = params[i];
     a.njobs = 0;
-    if (model == NERF_MODEL_NERF) {
-        a.dst = reinterpret_cast<__bf16*>(packed + lay::nerf::PACKED_FLOATS);
-        x3_bwd_job(a, 20, H + DE, H, HH, x3::D10);
-        x3_bwd_job(a, 18, H, H, H, x3::d_img(9));
-        for (int l = 8; l >= 6; --l) x3_bwd_job(a, 2 * l, H, H, H, x3::d_img(l));
-        x3_bwd_job(a, 10, H + PE, H, H, x3::d_img(5));
-        for (int l = 4; l >= 1; --l) x3_bwd_job(a, 2 * l, H, H, H, x3::d_img(l));
-    } else {
-        a.dst = reinterpret_cast<__bf16*>(packed + lay::siren::PACKED_FLOATS);
-        for (int l = 1; l <= 7; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3s::F_L1 + (size_t)(l - 1) * x3s::elems(H, H), false, true);
-        x3_fwd_job(a, 18, H, 0, H, H, x3s::F_FEAT, false, true);
-        x3_fwd_job(a, 20, H + DE, 0, HH, H, x3s::F_RGBA, false, false);
-        x3_fwd_job(a, 20, H + DE, H, HH, DE, x3s::F_RGBB, false, false);
-        x3_bwd_job(a, 20, H + DE, H, HH, x3s::D_RGB);
-        x3_bwd_job(a, 18, H, H, H, x3s::D_FEAT);
-        for (int l = 7; l >= 1; --l) x3_bwd_job(a, 2 * l, H, H, H, x3s::d_img(l));
-    }
+    a.dst = reinterpret_cast<__bf16*>(packed + lay::siren::PACKED_FLOATS);
+    for (int l = 1; l <= 7; ++l) x3_fwd_job(a, 2 * l, H, 0, H, H, x3s::F_L1 + (size_t)(l - 1) * x3s::elems(H, H), false, true);
+    x3_fwd_job(a, 18, H, 0, H, H, x3s::F_FEAT, false, true);
+    x3_fwd_job(a, 20, H + DE, 0, HH, H, x3s::F_RGBA, false, false);
+    x3_fwd_job(a, 20, H + DE, H, HH, DE, x3s::F_RGBB, false, false);
+    x3_bwd_job(a, 20, H + DE, H, HH, x3s::D_RGB);
+    x3_bwd_job(a, 18, H, H, H, x3s::D_FEAT);
+    for (int l = 7; l >= 1; --l) x3_bwd_job(a, 2 * l, H, H, H, x3s::d_img(l));
     pack_x3_kernel<<<dim3(a.njobs, 64), 256, 0, (hipStream_t)stream>>>(a);
-    if ((rc = nerf_check_launch("nerf_mlp_pack_x3"))) return rc;
-    if (model == NERF_MODEL_NERF)   // the forward's ring image
-        return nerf_mlp_pack_bf16x3(model, params, packed + lay::nerf::PACKED_FLOATS + x3::TOTAL_FLOATS, stream);
-    return NERF_OK;
+    return nerf_check_launch("nerf_mlp_pack_x3");
 }
 
 extern "C" int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const float* points, const float* dirs,
@@ -1007,7 +845,7 @@ extern "C" int nerf_mlp_fwd_x3(int model, const float* packed, int64_t M, const 
     X3FwdArgs a{packed, reinterpret_cast<const __bf16*>(packed + fp32_floats), M, mp, points, dirs, rays_o, rays_d,
                 t, S, t_per_ray, (float)near, (float)(far - near), colors, density, workspace};
     if (model == NERF_MODEL_NERF)   // 16-sample tiles, weights through an LDS ring (mlp_x3i.hip)
-        return nerf_x3i_fwd_train(packed + lay::nerf::PACKED_FLOATS + x3::TOTAL_FLOATS, M, points, dirs, rays_o, rays_d, t, S,
+        return nerf_x3i_fwd_train(packed + lay::nerf::PACKED_FLOATS, M, points, dirs, rays_o, rays_d, t, S,
                                   t_per_ray, near, far, colors, density, workspace, stream);
     if (int rc = nerf_set_lds(siren_fwd_x3_kernel, X3_FWD_LDS_BYTES)) return rc;
     siren_fwd_x3_kernel<<<(unsigned)tiles, X3_THREADS, X3_FWD_LDS_BYTES, (hipStream_t)stream>>>(a);
@@ -1029,13 +867,10 @@ extern "C" int nerf_mlp_bwd_data_x3(int model, const float* packed, int64_t M, c
     const size_t fp32_floats = model == NERF_MODEL_NERF ? lay::nerf::PACKED_FLOATS : lay::siren::PACKED_FLOATS;
     X3BwdArgs a{packed, reinterpret_cast<const __bf16*>(packed + fp32_floats), M, Mp, dcolors, ddensity, colors,
                 fwd_workspace, bwd_workspace};
-    int rc;
-    if (model == NERF_MODEL_NERF) {
-        if ((rc = nerf_set_lds(nerf_dgrad_x3_kernel, X3_BWD_LDS_BYTES))) return rc;
-        nerf_dgrad_x3_kernel<<<(unsigned)(Mp / TR), X3_THREADS, X3_BWD_LDS_BYTES, (hipStream_t)stream>>>(a);
-    } else {
-        if ((rc = nerf_set_lds(siren_dgrad_x3_kernel, X3_BWD_LDS_BYTES))) return rc;
-        siren_dgrad_x3_kernel<<<(unsigned)(Mp / TR), X3_THREADS, X3_BWD_LDS_BYTES, (hipStream_t)stream>>>(a);
-    }
+    if (model == NERF_MODEL_NERF)
+        return nerf_x3i_dgrad(packed + fp32_floats + nerf_mlp_packed_bf16x3_bytes(model) / 4, packed + lay::nerf::W11, M, dcolors,
+                              ddensity, colors, fwd_workspace, bwd_workspace, stream);
+    if (int rc = nerf_set_lds(siren_dgrad_x3_kernel, X3_BWD_LDS_BYTES)) return rc;
+    siren_dgrad_x3_kernel<<<(unsigned)(Mp / TR), X3_THREADS, X3_BWD_LDS_BYTES, (hipStream_t)stream>>>(a);
     return nerf_check_launch("nerf_mlp_bwd_data_x3");
 }

@@ -55,6 +55,25 @@
 // barriers per layer.  Streaming stores (nt) are 3 % slower, a request distance of five chunks changes nothing.
 #include "bf16_common.h"
 
+// Data-gradient chain of the NeRF model as a "network" of this kernel family (nerf/models.py:62-75 backwards, what
+// autograd derives for train.py:181): rgb_head.0's feature part, block2.8 (256 feature rows; the density row enters as a
+// rank-1 term), block2.6 .. block2.0 (the skip layer's feature part), block1.8 .. block1.2.  Input gradients of the first
+// layer are not part of the chain.
+constexpr int NERF_CHAIN_DGRAD = 16;
+namespace bf16k {
+template <> struct Net<NERF_CHAIN_DGRAD> {
+    static constexpr int NL = 10;
+    static constexpr LayerInfo LAYERS[NL_MAX] = {
+        {8, 8, ENC_NONE, 256, 128, 283, 20, -1, 1, -1, 0},  {8, 16, ENC_NONE, 256, 256, 256, 18, -1, 1, 18, 256},
+        {8, 16, ENC_NONE, 256, 256, 256, 16, -1, 1, -1, 0}, {8, 16, ENC_NONE, 256, 256, 256, 14, -1, 1, -1, 0},
+        {8, 16, ENC_NONE, 256, 256, 256, 12, -1, 1, -1, 0}, {8, 16, ENC_NONE, 256, 256, 319, 10, -1, 1, -1, 0},
+        {8, 16, ENC_NONE, 256, 256, 256, 8, -1, 1, -1, 0},  {8, 16, ENC_NONE, 256, 256, 256, 6, -1, 1, -1, 0},
+        {8, 16, ENC_NONE, 256, 256, 256, 4, -1, 1, -1, 0},  {8, 16, ENC_NONE, 256, 256, 256, 2, -1, 1, -1, 0},
+        {0, 0, ENC_NONE, 0, 0, 0, 0, -1, 0, -1, 0},         {0, 0, ENC_NONE, 0, 0, 0, 0, -1, 0, -1, 0},
+    };
+};
+}  // namespace bf16k
+
 using namespace bf16k;
 
 namespace {
@@ -175,7 +194,10 @@ __global__ __launch_bounds__(256) void pack_x3i_kernel(PackArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int col = k_column16(L, ks, q, j);
-                    if (col >= 0) v[j] = bf16_term(neg ? -w[col] : w[col], plane);
+                    if (col >= 0) {
+                        const float e = L.transposed ? a.src[L.wtensor][(size_t)col * L.ld + out] : w[col];
+                        v[j] = bf16_term(neg ? -e : e, plane);
+                    }
                 }
             }
         }
@@ -189,7 +211,11 @@ __global__ __launch_bounds__(256) void pack_x3i_kernel(PackArgs a) {
         const LayerInfo L = a.layers[l];
         const int out = 16 * (tile - a.bias_tile0[l]) + e;
         float b = 0.0f;
-        if (out < L.n_out) b = (L.last_row_tensor >= 0 && out == L.n_out - 1) ? a.src[L.last_row_tensor + 1][0] : a.src[L.wtensor + 1][out];
+        if (L.transposed) {
+            if (out < L.n_out && L.rank1_tensor >= 0) b = a.src[L.rank1_tensor][(size_t)L.rank1_row * L.ld + out];
+        } else if (out < L.n_out) {
+            b = (L.last_row_tensor >= 0 && out == L.n_out - 1) ? a.src[L.last_row_tensor + 1][0] : a.src[L.wtensor + 1][out];
+        }
         reinterpret_cast<float*>(a.dst + G::IMG_BYTES)[p] = ((a.neg_mask >> l) & 1u) ? -b : b;
     }
 }
@@ -347,7 +373,7 @@ __device__ __forceinline__ void mma_layer(Ring& r, int lane, f32x4 (&acc)[NOT_MA
 // |x| <= 1e5; pre-activations of sine layers fed by sines are bounded by sum|w| + |b|, first-layer ones by 30 times
 // that with coordinates in [-1, 1]): 8 vector instructions and a table read per value where the polynomial form has
 // 25 -- the epilogues run while no MFMA does, so every one of them is exposed.
-enum FragAct { FR_NONE = 0, FR_RELU = 1, FR_SIN = 2, FR_SIN30 = 3 };
+enum FragAct { FR_NONE = 0, FR_RELU = 1, FR_SIN = 2, FR_SIN30 = 3, FR_MASK = 4 };   // FR_MASK: data gradient, times (z > 0) from mw
 // OUT (training forward): FO_STORE also writes the activated tiles as fp32 to the workspace rows of this workgroup (rsrc;
 // voff = this lane's row and its 16-byte column group; tile ot at byte 64 ot of the row: 16 bytes per lane and tile, 64
 // contiguous bytes per sample); FO_MASK also collects the decisions z > 0 of a ReLU layer in mw: tile ot, register g at bit
@@ -385,6 +411,12 @@ __device__ __forceinline__ void to_frags_out(const f32x4 (&acc)[NOT_MAX], u32x4 
                 // the layer's image is negated (Geo::negated): relu(z) = max(0, -acc)
                 asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v0) : "v"(v0));
                 asm("v_max_f32_e64 %0, 0, -%1" : "=v"(v1) : "v"(v1));
+            }
+            if constexpr (ACT == FR_MASK) {   // the decisions as the forward recorded them (FO_MASK): 0 or all ones
+                const int idx = 4 * ((2 * s + (jp >> 1)) & 7) + 2 * (jp & 1);
+                const int k0 = __builtin_amdgcn_sbfe((int)mw[s >> 2], 31 - idx, 1), k1 = __builtin_amdgcn_sbfe((int)mw[s >> 2], 30 - idx, 1);
+                v0 = __builtin_bit_cast(float, __builtin_bit_cast(int, v0) & k0);
+                v1 = __builtin_bit_cast(float, __builtin_bit_cast(int, v1) & k1);
             }
             h[2 * jp] = v0;
             h[2 * jp + 1] = v1;
@@ -659,6 +691,167 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
     }
 }
 
+
+// ---- data gradient (NeRF model) ---------------------------------------------------------------------
+struct DgradArgs {
+    const unsigned char* img;   // ring image of Net<NERF_CHAIN_DGRAD>
+    const float* w11;           // rgb_head.2 weight [3][128], fp32
+    int64_t M;
+    size_t Mp;
+    const float* dcolors;
+    const float* ddensity;
+    const float* colors;
+    const float* ws;            // the forward's workspace
+    float* bw;                  // layer gradients dz0..dz8 | dz9 | dz10 | dz11 | dsig (mlp_layout.h)
+};
+
+// The chain dz10 -> dz9 -> dz8 -> ... -> dz0 on the forward kernel's structure: dZ^T of a layer is the B operand, chained
+// in registers, the transposed weights stream through the ring.  Every layer gradient goes to the backward workspace from
+// the registers, as the forward's activations do; the ReLU decisions are the words the forward stored for exactly this
+// lane (same samples, same tile and register order), all nine fetched before the first chunk is requested.
+__global__ __launch_bounds__(WG_THREADS, 2) void dgrad_x3i_kernel(DgradArgs a) {
+    using G = Geo<NERF_CHAIN_DGRAD>;
+    using namespace lay;
+    using namespace lay::nerf;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* ring_lds = smem + TAB_BYTES;
+    float* bias_lds = reinterpret_cast<float*>(ring_lds + NBUF * CHUNK_BYTES);   // 16 tiles: the density row of block2.8
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4;
+    const size_t m0g = (size_t)blockIdx.x * WG_SAMPLES;
+    const int row_local = wave * 16 + (lane & 15);
+    const size_t m = m0g + row_local;
+    const bool valid = m < (size_t)a.M;
+    const size_t rows = a.Mp - m0g < (size_t)WG_SAMPLES ? a.Mp - m0g : (size_t)WG_SAMPLES;
+    const auto field_of = [&](const float* base, size_t off, int width) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + off * a.Mp + m0g * width, 0, (int)rows * width * 4, 0x00020000);
+    };
+
+    // ---- ordinary loads first (the compiler waits for everything in flight at the first use of one of them)
+    const float* bias_g = reinterpret_cast<const float*>(a.img + G::IMG_BYTES) + G::bias_tile0(1) * 16;
+    if (tid < 256) bias_lds[tid] = bias_g[tid];
+    float dz11[3] = {0.f, 0.f, 0.f}, ds = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float col = a.colors[m * 3 + c];
+            dz11[c] = a.dcolors[m * 3 + c] * col * (1.0f - col);            // sigmoid'
+        }
+        ds = a.ws[WS_SRAW * a.Mp + m] > 0.0f ? a.ddensity[m] : 0.0f;       // relu' of the density output
+    }
+    // ReLU decisions of h0..h8 (rows behind the padded sample count read as 0)
+    u32x2 mk[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l)
+        mk[l] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(field_of(a.ws, WS_MASK + 8 * (size_t)l, 8), row_local * 32 + q * 8, 0, 0));
+    // g (the 128 ReLU outputs of rgb_head.0) and rgb_head.2's weights at this lane's fragment features: k-step s, element j
+    // = feature 32 s + 4 q + j (j < 4), 32 s + 16 + 4 q + (j - 4)
+    f32x4 gv[4][2], wv[3][4][2];
+    {
+        const __amdgpu_buffer_rsrc_t g_rsrc = field_of(a.ws, WS_G, HH);
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w11), 0, 3 * HH * 4, 0x00020000);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                gv[s][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, row_local * HH * 4 + q * 16 + (32 * s + 16 * t) * 4, 0, 0));
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    wv[c][s][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, q * 16 + (c * HH + 32 * s + 16 * t) * 4, 0, 0));
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr auto tail = [](int l) { return G::NCHUNK - G::chunk0(l + 1) < AHEAD ? G::NCHUNK - G::chunk0(l + 1) : AHEAD; };
+    Ring ring{a.img, ring_lds, 0, (unsigned)(PER_CHUNK * 1024 * wave + 16 * lane), wave, G::NCHUNK, (int)G::IMG_BYTES};
+#pragma unroll
+    for (int c = 0; c < AHEAD; ++c) ring_issue(ring, c);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- head: dz11, dsig; dz10 = (g > 0) * (dz11 . W11) as fragments and to the workspace (head_bwd of mlp_bwd.hip)
+    const auto put = [](float v, __amdgpu_buffer_rsrc_t rsrc, int voff) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff, 0, 0);
+    };
+    if (q == 0) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{dz11[0], dz11[1], dz11[2], 0.0f}), field_of(a.bw, BW_DZ11, 4),
+                                               row_local * 16, 0, 0);
+        put(ds, field_of(a.bw, BW_DSIG, 1), row_local * 4);
+    }
+    u32x4 X[3][8];
+    {
+        const __amdgpu_buffer_rsrc_t dz10 = field_of(a.bw, BW_DZ10, HH);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = dz11[0] * wv[0][s][t][e] + dz11[1] * wv[1][s][t][e] + dz11[2] * wv[2][s][t][e];
+                    d[e] = gv[s][t][e] > 0.0f ? x : 0.0f;
+                    v[4 * t + e] = d[e];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), dz10, row_local * HH * 4 + q * 16 + (32 * s + 16 * t) * 4, 0, 0);
+            }
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                unsigned tm[3];
+                split2<3>(v[2 * jp], v[2 * jp + 1], tm);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) X[p][s][jp] = tm[p];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * PER_CHUNK) : "memory");   // own pieces of chunk 0, own LDS writes
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x4 acc[NOT_MAX];
+    u32x4 XE[3][2];   // (no encoding k-steps in this chain)
+    const auto zero_acc = [&]() {
+#pragma unroll
+        for (int ot = 0; ot < 16; ++ot) acc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    constexpr int N_HEAD_STORES = 10, N_DZ_STORES = 16;
+    const int voff_h = row_local * H * 4 + q * 16;
+    unsigned none[2] = {0u, 0u};
+    // rgb_head.0, feature part: dz9 (block2.8 has no activation)
+    zero_acc();
+    mma_layer<16, 4, 0, tail(0), 0, N_HEAD_STORES>(ring, lane, acc, X, XE);
+    to_frags_out<8, FR_NONE, FO_STORE>(acc, X, field_of(a.bw, BW_DZ9, H), voff_h, none);
+    // block2.8: the feature rows on the matrix pipe, the density row as the rank-1 term dsig[sample] * w[feature]
+#pragma unroll
+    for (int ot = 0; ot < 16; ++ot) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(bias_lds + ot * 16 + q * 4);
+        acc[ot] = f32x4{ds * w[0], ds * w[1], ds * w[2], ds * w[3]};
+    }
+    mma_layer<16, 8, 0, tail(1), 0, N_DZ_STORES>(ring, lane, acc, X, XE);
+    {
+        unsigned mw[2] = {mk[8][0], mk[8][1]};
+        to_frags_out<8, FR_MASK, FO_STORE>(acc, X, field_of(a.bw, BW_DZ + 8 * (size_t)H, H), voff_h, mw);
+    }
+    // block2.6 .. block1.2: dz(l-1) = (h(l-1) > 0) * (dz(l) W(l)); the decisions of the next layer move to the front of mk
+#pragma unroll 1
+    for (int l = 8; l >= 2; --l) {
+        zero_acc();
+        mma_layer<16, 8, 0, tail(2), 0, N_DZ_STORES>(ring, lane, acc, X, XE);
+        unsigned mw[2] = {mk[7][0], mk[7][1]};
+#pragma unroll
+        for (int i = 7; i >= 1; --i) mk[i] = mk[i - 1];
+        to_frags_out<8, FR_MASK, FO_STORE>(acc, X, field_of(a.bw, BW_DZ + (size_t)(l - 1) * H, H), voff_h, mw);
+    }
+    // block1.2: dz0 ends the chain (its fragments are not needed)
+    zero_acc();
+    mma_layer<16, 8, 0, 0, 0, N_DZ_STORES>(ring, lane, acc, X, XE);
+    {
+        unsigned mw[2] = {mk[7][0], mk[7][1]};
+        to_frags_out<8, FR_MASK, FO_STORE>(acc, X, field_of(a.bw, BW_DZ, H), voff_h, mw);
+    }
+    static_assert(G::NL == 10 && tail(9) == 0 && tail(8) == AHEAD, "the chain's last layer ends the stream");
+}
+
 template <int MODEL>
 int pack_image(const float* const* params, void* packed, void* stream, const char* who) {
     using G = Geo<MODEL>;
@@ -708,6 +901,23 @@ __attribute__((visibility("hidden"))) int nerf_x3i_fwd_train(const void* image, 
               (float)near, (float)(far - near), colors, density, workspace, lay::padded_samples(M)};
     if (int rc = nerf_set_lds(fwd_x3i_kernel<NERF_MODEL_NERF, false, true>, LDS_BYTES)) return rc;
     fwd_x3i_kernel<NERF_MODEL_NERF, false, true><<<(unsigned)groups, WG_THREADS, LDS_BYTES, (hipStream_t)stream>>>(a);
+    return nerf_check_launch(who);
+}
+
+// Data-gradient chain of the bf16x3 training mode (NeRF model), called by nerf_mlp_pack_x3 / nerf_mlp_bwd_data_x3.
+__attribute__((visibility("hidden"))) size_t nerf_x3i_dgrad_image_bytes() { return Geo<NERF_CHAIN_DGRAD>::PACKED_BYTES; }
+__attribute__((visibility("hidden"))) int nerf_x3i_dgrad_pack(const float* const* params, void* image, void* stream) {
+    return pack_image<NERF_CHAIN_DGRAD>(params, image, stream, "nerf_mlp_pack_x3");
+}
+__attribute__((visibility("hidden"))) int nerf_x3i_dgrad(const void* image, const float* w11, int64_t M, const float* dcolors,
+                                                         const float* ddensity, const float* colors, const float* fwd_workspace,
+                                                         float* bwd_workspace, void* stream) {
+    const char* who = "nerf_mlp_bwd_data_x3";
+    const int64_t groups = ceil_div64(M, WG_SAMPLES);
+    if (groups >= (1ll << 31)) return nerf_fail(NERF_E_ARG, "%s: too many samples", who);
+    DgradArgs a{static_cast<const unsigned char*>(image), w11, M, lay::padded_samples(M), dcolors, ddensity, colors, fwd_workspace, bwd_workspace};
+    if (int rc = nerf_set_lds(dgrad_x3i_kernel, LDS_BYTES)) return rc;
+    dgrad_x3i_kernel<<<(unsigned)groups, WG_THREADS, LDS_BYTES, (hipStream_t)stream>>>(a);
     return nerf_check_launch(who);
 }
 
