@@ -47,13 +47,14 @@ PMC_KERNEL = {("nerf", "mlp_fwd_train"): ("nerf_fwd_kernel", ("true",)), ("nerf"
               ("nerf", "mlp_fwd_infer"): ("nerf_fwd_kernel", ("false", "false")),
               ("siren", "mlp_fwd_train"): ("siren_fwd_kernel", ("true",)), ("siren", "mlp_bwd_data"): ("siren_dgrad_kernel", ()),
               ("siren", "mlp_fwd_infer"): ("siren_fwd_kernel", ("false", "false")),
-              ("nerf", "mlp_fwd_train_x3"): ("nerf_fwd_x3_kernel", ()), ("nerf", "mlp_bwd_data_x3"): ("nerf_dgrad_x3_kernel", ())}
+              # (template arguments: model 0 = NeRF, all outputs, with the workspace)
+              ("nerf", "mlp_fwd_train_x3"): ("fwd_x3i_kernel", ("0", "false", "true")), ("nerf", "mlp_bwd_data_x3"): ("dgrad_x3i_kernel", ("0",))}
 # HBM bytes per MLP evaluation the kernels move BY DESIGN (csrc/mlp_layout.h): the forward writes its workspace
 # (2857 / 4517 floats per sample) and reads 24 B of ray data per 256 samples; the data gradient writes every layer's
 # dY (2693 / 2437 floats) and reads the head's inputs, the ReLU mask words or the stored cosines.  The packed
 # weights (5 MB) stay in the caches.
 DESIGN_BYTES = {("nerf", "mlp_fwd_train"): 4 * 2857, ("nerf", "mlp_bwd_data"): 4 * (2693 + 128 + 72 + 8),
-                ("nerf", "mlp_fwd_train_x3"): 4 * 2857 + 4 * 256, ("nerf", "mlp_bwd_data_x3"): 4 * (2693 + 128 + 72 + 8),   # (+ h8 read back once)
+                ("nerf", "mlp_fwd_train_x3"): 4 * 2857, ("nerf", "mlp_bwd_data_x3"): 4 * (2693 + 128 + 72 + 8),
                 ("siren", "mlp_fwd_train"): 4 * 4517, ("siren", "mlp_bwd_data"): 4 * (2437 + 8 * 256 + 256 + 8)}
 
 

@@ -59,8 +59,8 @@
 // autograd derives for train.py:181): rgb_head.0's feature part, block2.8 (256 feature rows; the density row enters as a
 // rank-1 term), block2.6 .. block2.0 (the skip layer's feature part), block1.8 .. block1.2.  Input gradients of the first
 // layer are not part of the chain.
-constexpr int NERF_CHAIN_DGRAD = 16;
 namespace bf16k {
+constexpr int NERF_CHAIN_DGRAD = 16;
 template <> struct Net<NERF_CHAIN_DGRAD> {
     static constexpr int NL = 10;
     static constexpr LayerInfo LAYERS[NL_MAX] = {
@@ -69,6 +69,20 @@ template <> struct Net<NERF_CHAIN_DGRAD> {
         {8, 16, ENC_NONE, 256, 256, 256, 12, -1, 1, -1, 0}, {8, 16, ENC_NONE, 256, 256, 319, 10, -1, 1, -1, 0},
         {8, 16, ENC_NONE, 256, 256, 256, 8, -1, 1, -1, 0},  {8, 16, ENC_NONE, 256, 256, 256, 6, -1, 1, -1, 0},
         {8, 16, ENC_NONE, 256, 256, 256, 4, -1, 1, -1, 0},  {8, 16, ENC_NONE, 256, 256, 256, 2, -1, 1, -1, 0},
+        {0, 0, ENC_NONE, 0, 0, 0, 0, -1, 0, -1, 0},         {0, 0, ENC_NONE, 0, 0, 0, 0, -1, 0, -1, 0},
+    };
+};
+// Siren (nerf/models.py:185-203 backwards): rgb_head.0's feature part, feature_remap (the density branch enters as a
+// rank-1 term), block1.7 .. block1.1.
+constexpr int SIREN_CHAIN_DGRAD = 17;
+template <> struct Net<SIREN_CHAIN_DGRAD> {
+    static constexpr int NL = 9;
+    static constexpr LayerInfo LAYERS[NL_MAX] = {
+        {8, 8, ENC_NONE, 256, 128, 283, 20, -1, 1, -1, 0},  {8, 16, ENC_NONE, 256, 256, 256, 18, -1, 1, 16, 0},
+        {8, 16, ENC_NONE, 256, 256, 256, 14, -1, 1, -1, 0}, {8, 16, ENC_NONE, 256, 256, 256, 12, -1, 1, -1, 0},
+        {8, 16, ENC_NONE, 256, 256, 256, 10, -1, 1, -1, 0}, {8, 16, ENC_NONE, 256, 256, 256, 8, -1, 1, -1, 0},
+        {8, 16, ENC_NONE, 256, 256, 256, 6, -1, 1, -1, 0},  {8, 16, ENC_NONE, 256, 256, 256, 4, -1, 1, -1, 0},
+        {8, 16, ENC_NONE, 256, 256, 256, 2, -1, 1, -1, 0},  {0, 0, ENC_NONE, 0, 0, 0, 0, -1, 0, -1, 0},
         {0, 0, ENC_NONE, 0, 0, 0, 0, -1, 0, -1, 0},         {0, 0, ENC_NONE, 0, 0, 0, 0, -1, 0, -1, 0},
     };
 };
@@ -373,19 +387,44 @@ __device__ __forceinline__ void mma_layer(Ring& r, int lane, f32x4 (&acc)[NOT_MA
 // |x| <= 1e5; pre-activations of sine layers fed by sines are bounded by sum|w| + |b|, first-layer ones by 30 times
 // that with coordinates in [-1, 1]): 8 vector instructions and a table read per value where the polynomial form has
 // 25 -- the epilogues run while no MFMA does, so every one of them is exposed.
-enum FragAct { FR_NONE = 0, FR_RELU = 1, FR_SIN = 2, FR_SIN30 = 3, FR_MASK = 4 };   // FR_MASK: data gradient, times (z > 0) from mw
+// Data gradient: FR_MASK multiplies by the ReLU decisions in mw, FR_DERIV by the sine layer's derivative tile, read from
+// rsrc2 at the places of the values themselves.
+enum FragAct { FR_NONE = 0, FR_RELU = 1, FR_SIN = 2, FR_SIN30 = 3, FR_MASK = 4, FR_DERIV = 5 };
 // OUT (training forward): FO_STORE also writes the activated tiles as fp32 to the workspace rows of this workgroup (rsrc;
 // voff = this lane's row and its 16-byte column group; tile ot at byte 64 ot of the row: 16 bytes per lane and tile, 64
 // contiguous bytes per sample); FO_MASK also collects the decisions z > 0 of a ReLU layer in mw: tile ot, register g at bit
-// 31 - (4 (ot & 7) + g) of mw[ot >> 3].
-enum FragOut { FO_NONE = 0, FO_STORE = 1, FO_MASK = 2 };
+// 31 - (4 (ot & 7) + g) of mw[ot >> 3]; FO_DERIV also writes a sine layer's derivative w0 cos(w0 z) to rsrc2, value by
+// value where the activation goes in rsrc.
+enum FragOut { FO_NONE = 0, FO_STORE = 1, FO_MASK = 2, FO_DERIV = 3 };
+// FR_DERIV: the derivative tiles of a layer travel through four slots of two tiles (one tile pair each).  The first
+// DERIV_AHEAD pairs are requested before the layer's MFMA loop (deriv_prefetch), the next two at the start of the
+// epilogue, pair s + 4 when pair s has been used.
+constexpr int DERIV_AHEAD = 2;
+struct DerivTiles {
+    f32x4 t[4][2];
+};
+__device__ __forceinline__ void deriv_load(DerivTiles& d, int s, __amdgpu_buffer_rsrc_t rsrc2, int voff) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        d.t[s & 3][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc2, voff + (2 * s + t) * 64, 0, 0));
+}
+__device__ __forceinline__ void deriv_prefetch(DerivTiles& d, __amdgpu_buffer_rsrc_t rsrc2, int voff) {
+#pragma unroll
+    for (int s = 0; s < DERIV_AHEAD; ++s) deriv_load(d, s, rsrc2, voff);
+}
 template <int NPAIR, int ACT, int OUT>
 __device__ __forceinline__ void to_frags_out(const f32x4 (&acc)[NOT_MAX], u32x4 (&X)[3][8], __amdgpu_buffer_rsrc_t rsrc, int voff,
-                                             unsigned (&mw)[2]) {
+                                             unsigned (&mw)[2], __amdgpu_buffer_rsrc_t rsrc2, DerivTiles& dv) {
     static_assert(OUT != FO_MASK || ACT == FR_RELU, "mask bits are the signs of negated ReLU pre-activations");
+    static_assert(OUT != FO_DERIV || ACT == FR_SIN || ACT == FR_SIN30, "derivative of a sine layer");
+    if constexpr (ACT == FR_DERIV) {
+#pragma unroll
+        for (int s = DERIV_AHEAD; s < 4 && s < NPAIR; ++s) deriv_load(dv, s, rsrc2, voff);
+    }
 #pragma unroll
     for (int s = 0; s < NPAIR; ++s) {
         f32x2 v[4];
+        [[maybe_unused]] f32x2 cs[4];
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) v[jp] = f32x2{acc[2 * s + (jp >> 1)][2 * (jp & 1)], acc[2 * s + (jp >> 1)][2 * (jp & 1) + 1]};
         if constexpr (ACT == FR_SIN || ACT == FR_SIN30) {
@@ -395,8 +434,8 @@ __device__ __forceinline__ void to_frags_out(const f32x4 (&acc)[NOT_MAX], u32x4 
                 dev::sincos_tab_issue(ACT == FR_SIN30 ? f32x2{mul_rn(30.0f, v[jp][0]), mul_rn(30.0f, v[jp][1])} : v[jp], pr[jp]);
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) {
-                f32x2 cs;
-                dev::sincos_tab_finish(pr[jp], v[jp], cs);
+                dev::sincos_tab_finish(pr[jp], v[jp], cs[jp]);
+                if constexpr (ACT == FR_SIN30) cs[jp] = f32x2{30.0f * cs[jp][0], 30.0f * cs[jp][1]};
             }
         }
         float h[8];
@@ -418,6 +457,10 @@ __device__ __forceinline__ void to_frags_out(const f32x4 (&acc)[NOT_MAX], u32x4 
                 v0 = __builtin_bit_cast(float, __builtin_bit_cast(int, v0) & k0);
                 v1 = __builtin_bit_cast(float, __builtin_bit_cast(int, v1) & k1);
             }
+            if constexpr (ACT == FR_DERIV) {
+                v0 *= dv.t[s & 3][jp >> 1][2 * (jp & 1)];
+                v1 *= dv.t[s & 3][jp >> 1][2 * (jp & 1) + 1];
+            }
             h[2 * jp] = v0;
             h[2 * jp + 1] = v1;
             unsigned tm[3];
@@ -433,7 +476,27 @@ __device__ __forceinline__ void to_frags_out(const f32x4 (&acc)[NOT_MAX], u32x4 
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{h[4 * t], h[4 * t + 1], h[4 * t + 2], h[4 * t + 3]}),
                                                        rsrc, voff + (2 * s + t) * 64, 0, 0);
         }
+        if constexpr (OUT == FO_DERIV) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{cs[2 * t][0], cs[2 * t][1], cs[2 * t + 1][0], cs[2 * t + 1][1]}),
+                                                       rsrc2, voff + (2 * s + t) * 64, 0, 0);
+        }
+        if constexpr (ACT == FR_DERIV)
+            if (s + 4 < NPAIR) deriv_load(dv, s + 4, rsrc2, voff);
     }
+}
+template <int NPAIR, int ACT, int OUT>
+__device__ __forceinline__ void to_frags_out(const f32x4 (&acc)[NOT_MAX], u32x4 (&X)[3][8], __amdgpu_buffer_rsrc_t rsrc, int voff,
+                                             unsigned (&mw)[2], __amdgpu_buffer_rsrc_t rsrc2) {
+    static_assert(ACT != FR_DERIV, "the data gradient passes its derivative tiles");
+    DerivTiles none;
+    to_frags_out<NPAIR, ACT, OUT>(acc, X, rsrc, voff, mw, rsrc2, none);
+}
+template <int NPAIR, int ACT, int OUT>
+__device__ __forceinline__ void to_frags_out(const f32x4 (&acc)[NOT_MAX], u32x4 (&X)[3][8], __amdgpu_buffer_rsrc_t rsrc, int voff,
+                                             unsigned (&mw)[2]) {
+    to_frags_out<NPAIR, ACT, OUT>(acc, X, rsrc, voff, mw, rsrc);
 }
 template <int NPAIR, int ACT>
 __device__ __forceinline__ void to_frags(const f32x4 (&acc)[NOT_MAX], u32x4 (&X)[3][8]) {
@@ -461,14 +524,15 @@ __device__ __forceinline__ void vals_to_frags(const float (&v)[N], u32x4 (&X)[3]
 
 // DENSITY_ONLY (colors == NULL): the stream ends with the layer that holds the density row -- the coarse pass of a
 // hierarchical render without gradients feeds only the re-sampling.
-// TRAIN (NeRF model): also fills the activation workspace that the data-gradient and weight-gradient kernels of the
-// bf16x3 training mode read (pe, de, h0..h8, f, g, the density pre-activation, the ReLU decisions of h0..h8), every
-// value straight from the registers that hold it.  ReLU decisions: one 8-byte word per lane and layer -- sample c of the
+// TRAIN: also fills the activation workspace that the data-gradient and weight-gradient kernels of the bf16x3 training
+// mode read (mlp_layout.h; NeRF: pe, de, h0..h8, f, g, the density pre-activation, the ReLU decisions of h0..h8; Siren: x,
+// de, h0..h7 and their derivatives w0 cos(w0 z), f, g and its derivative, the density pre-activation), every value
+// straight from the registers that hold it.  ReLU decisions: one 8-byte word per lane and layer -- sample c of the
 // wave's 16, lane group q: bit 31 - (4 (ot & 7) + g) of word ot >> 3 is the decision of feature 16 ot + 4 q + g -- at
 // byte 32 m + 8 q of the layer's mask field (32 bytes per sample m).
 template <int MODEL, bool DENSITY_ONLY, bool TRAIN = false>
 __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
-    static_assert(!TRAIN || (MODEL == NERF_MODEL_NERF && !DENSITY_ONLY), "training forward: NeRF model, all outputs");
+    static_assert(!TRAIN || !DENSITY_ONLY, "training forward: all outputs");
     using G = Geo<MODEL>;
     constexpr auto bias_tile0 = [](int l) { return G::bias_tile0(l); };
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -564,6 +628,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = q == 0 ? x[c] : 0.0f;
         vals_to_frags<8, 2>(v, E0);
+        if constexpr (TRAIN)
+            if (q == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{x[0], x[1], x[2], 0.0f}), field(lay::siren::WS_X, 4),
+                                                       row_local * 16, 0, 0);
     }
     // publish chunk 0 and the bias image: own pieces of chunk 0 landed (chunks 1, 2 stay in flight),
     // own LDS writes done, then the barrier
@@ -584,7 +652,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
         vals_to_frags<8, 2>(v, DE);
         if constexpr (TRAIN) {
             // de in the reference's column order; columns 27..31 (padding of the 32-wide field) zero
-            const __amdgpu_buffer_rsrc_t de = field(lay::nerf::WS_DE, lay::DE_P);
+            const __amdgpu_buffer_rsrc_t de = field(MODEL == NERF_MODEL_NERF ? lay::nerf::WS_DE : lay::siren::WS_DE, lay::DE_P);
             const int row = row_local * lay::DE_P * 4;
 #pragma unroll
             for (int e = 0; e < 6; ++e) put(v[e], de, row + 24 * q + (3 + e) * 4);
@@ -657,14 +725,21 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
     } else {
         // nerf/models.py:185-203: sin(30 (W0 x + b0)), seven sin(W h + b) layers, then feature_remap + density_branch
         // as one 17-tile layer, the 283 -> 128 sine layer of the rgb head and its 128 -> 3 output layer
+        constexpr int N_SIN_STORES = TRAIN ? 32 : 0;   // activation and derivative
+        [[maybe_unused]] unsigned none[2];
+        [[maybe_unused]] const int voff_h = row_local * lay::H * 4 + q * 16;
         init_bias<16>(acc, bias_lds, bias_tile0(0), q);
-        mma_layer<16, 0, 1, tail(0)>(ring, lane, acc, X, E0);
-        to_frags<8, FR_SIN30>(acc, X);
+        mma_layer<16, 0, 1, tail(0), 0, (TRAIN ? 1 : 0)>(ring, lane, acc, X, E0);
+        if constexpr (TRAIN) to_frags_out<8, FR_SIN30, FO_DERIV>(acc, X, field(lay::siren::WS_H, lay::H), voff_h, none, field(lay::siren::WS_C, lay::H));
+        else to_frags<8, FR_SIN30>(acc, X);
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             init_bias<16>(acc, bias_lds, 16 * l, q);
-            mma_layer<16, 8, 0, tail(7)>(ring, lane, acc, X, E0);
-            to_frags<8, FR_SIN>(acc, X);
+            mma_layer<16, 8, 0, tail(7), 0, N_SIN_STORES>(ring, lane, acc, X, E0);
+            if constexpr (TRAIN)
+                to_frags_out<8, FR_SIN, FO_DERIV>(acc, X, field(lay::siren::WS_H + (size_t)l * lay::H, lay::H), voff_h, none,
+                                                  field(lay::siren::WS_C + (size_t)l * lay::H, lay::H));
+            else to_frags<8, FR_SIN>(acc, X);
         }
         init_bias<17>(acc, bias_lds, bias_tile0(8), q);
         if constexpr (DENSITY_ONLY) {
@@ -672,14 +747,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
             if (valid && q == 0) a.density[m] = fmaxf(acc[16][0], 0.0f) * 10.0f;
             return;
         }
-        mma_layer<17, 8, 0, tail(8)>(ring, lane, acc, X, E0);
+        mma_layer<17, 8, 0, tail(8), 0, N_SIN_STORES>(ring, lane, acc, X, E0);
         dens = fmaxf(acc[16][0], 0.0f) * 10.0f;           // relu(sigma) * sigma_mul (models.py:193)
-        to_frags<8, FR_NONE>(acc, X);
+        if constexpr (TRAIN) {
+            if (q == 0) put(acc[16][0], field(lay::siren::WS_SRAW, 1), row_local * 4);
+            to_frags_out<8, FR_NONE, FO_STORE>(acc, X, field(lay::siren::WS_F, lay::H), voff_h, none);
+        } else {
+            to_frags<8, FR_NONE>(acc, X);
+        }
         u32x4 DE[3][2];
         direction_frags(DE);
         init_bias<8>(acc, bias_lds, bias_tile0(9), q);
-        mma_layer<8, 8, 1, tail(9)>(ring, lane, acc, X, DE);
-        to_frags<4, FR_SIN>(acc, X);
+        mma_layer<8, 8, 1, tail(9), 0, (TRAIN ? 17 + N_DE_STORES : 0)>(ring, lane, acc, X, DE);
+        if constexpr (TRAIN)
+            to_frags_out<4, FR_SIN, FO_DERIV>(acc, X, field(lay::siren::WS_G, lay::HH), row_local * lay::HH * 4 + q * 16, none,
+                                              field(lay::siren::WS_CG, lay::HH));
+        else to_frags<4, FR_SIN>(acc, X);
         init_bias<1>(acc, bias_lds, bias_tile0(10), q);
         mma_layer<1, 4, 0, 0>(ring, lane, acc, X, DE);
     }
@@ -692,30 +775,36 @@ __global__ __launch_bounds__(WG_THREADS, 2) void fwd_x3i_kernel(FwdArgs a) {
 }
 
 
-// ---- data gradient (NeRF model) ---------------------------------------------------------------------
+// ---- data gradient -----------------------------------------------------------------------------------
 struct DgradArgs {
-    const unsigned char* img;   // ring image of Net<NERF_CHAIN_DGRAD>
-    const float* w11;           // rgb_head.2 weight [3][128], fp32
+    const unsigned char* img;   // ring image of the model's data-gradient chain
+    const float* wout;          // the output layer's weight [3][128], fp32
     int64_t M;
     size_t Mp;
     const float* dcolors;
     const float* ddensity;
     const float* colors;
     const float* ws;            // the forward's workspace
-    float* bw;                  // layer gradients dz0..dz8 | dz9 | dz10 | dz11 | dsig (mlp_layout.h)
+    float* bw;                  // layer gradients (mlp_layout.h)
 };
 
-// The chain dz10 -> dz9 -> dz8 -> ... -> dz0 on the forward kernel's structure: dZ^T of a layer is the B operand, chained
-// in registers, the transposed weights stream through the ring.  Every layer gradient goes to the backward workspace from
-// the registers, as the forward's activations do; the ReLU decisions are the words the forward stored for exactly this
-// lane (same samples, same tile and register order), all nine fetched before the first chunk is requested.
+// The chain d(rgb hidden) -> d(features) -> d(last hidden layer) -> ... -> dz0 on the forward kernel's structure: dZ^T of a
+// layer is the B operand, chained in registers, the transposed weights stream through the ring.  Every layer gradient
+// goes to the backward workspace from the registers, as the forward's activations do.  NeRF: the ReLU decisions are the
+// words the forward stored for exactly this lane (same samples, same tile and register order), all nine fetched before
+// the first chunk is requested.  Siren: the derivative tiles are read in the epilogues, where the forward wrote them.
+template <int MODEL>
 __global__ __launch_bounds__(WG_THREADS, 2) void dgrad_x3i_kernel(DgradArgs a) {
-    using G = Geo<NERF_CHAIN_DGRAD>;
+    constexpr bool IS_NERF = MODEL == NERF_MODEL_NERF;
+    using G = Geo<IS_NERF ? NERF_CHAIN_DGRAD : SIREN_CHAIN_DGRAD>;
     using namespace lay;
-    using namespace lay::nerf;
+    constexpr size_t WS_G = IS_NERF ? nerf::WS_G : siren::WS_G, WS_SRAW = IS_NERF ? nerf::WS_SRAW : siren::WS_SRAW;
+    constexpr size_t BW_DZ = 0, BW_DZF = IS_NERF ? nerf::BW_DZ9 : siren::BW_DZF, BW_DZR = IS_NERF ? nerf::BW_DZ10 : siren::BW_DZR;
+    constexpr size_t BW_DZO = IS_NERF ? nerf::BW_DZ11 : siren::BW_DZO, BW_DSIG = IS_NERF ? nerf::BW_DSIG : siren::BW_DSIG;
+    constexpr int LAST_HIDDEN = IS_NERF ? 8 : 7;            // the layer whose output feeds the features and the density
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* ring_lds = smem + TAB_BYTES;
-    float* bias_lds = reinterpret_cast<float*>(ring_lds + NBUF * CHUNK_BYTES);   // 16 tiles: the density row of block2.8
+    float* bias_lds = reinterpret_cast<float*>(ring_lds + NBUF * CHUNK_BYTES);   // 16 tiles: the density row's weights
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4;
@@ -731,26 +820,30 @@ __global__ __launch_bounds__(WG_THREADS, 2) void dgrad_x3i_kernel(DgradArgs a) {
     // ---- ordinary loads first (the compiler waits for everything in flight at the first use of one of them)
     const float* bias_g = reinterpret_cast<const float*>(a.img + G::IMG_BYTES) + G::bias_tile0(1) * 16;
     if (tid < 256) bias_lds[tid] = bias_g[tid];
-    float dz11[3] = {0.f, 0.f, 0.f}, ds = 0.f;
+    float dzo[3] = {0.f, 0.f, 0.f}, ds = 0.f;
     if (valid) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float col = a.colors[m * 3 + c];
-            dz11[c] = a.dcolors[m * 3 + c] * col * (1.0f - col);            // sigmoid'
+            dzo[c] = a.dcolors[m * 3 + c] * col * (1.0f - col);            // sigmoid'
         }
-        ds = a.ws[WS_SRAW * a.Mp + m] > 0.0f ? a.ddensity[m] : 0.0f;       // relu' of the density output
+        // relu' of the density output (Siren: times sigma_mul, models.py:193)
+        ds = a.ws[WS_SRAW * a.Mp + m] > 0.0f ? a.ddensity[m] * (IS_NERF ? 1.0f : 10.0f) : 0.0f;
     }
     // ReLU decisions of h0..h8 (rows behind the padded sample count read as 0)
-    u32x2 mk[9];
+    [[maybe_unused]] u32x2 mk[9];
+    if constexpr (IS_NERF) {
 #pragma unroll
-    for (int l = 0; l < 9; ++l)
-        mk[l] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(field_of(a.ws, WS_MASK + 8 * (size_t)l, 8), row_local * 32 + q * 8, 0, 0));
-    // g (the 128 ReLU outputs of rgb_head.0) and rgb_head.2's weights at this lane's fragment features: k-step s, element j
-    // = feature 32 s + 4 q + j (j < 4), 32 s + 16 + 4 q + (j - 4)
+        for (int l = 0; l < 9; ++l)
+            mk[l] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(field_of(a.ws, nerf::WS_MASK + 8 * (size_t)l, 8), row_local * 32 + q * 8, 0, 0));
+    }
+    // the 128 outputs of the rgb hidden layer (NeRF: g, whose sign decides; Siren: the derivative cos z) and the output
+    // layer's weights at this lane's fragment features: k-step s, element j = feature 32 s + 4 q + j (j < 4),
+    // 32 s + 16 + 4 q + (j - 4)
     f32x4 gv[4][2], wv[3][4][2];
     {
-        const __amdgpu_buffer_rsrc_t g_rsrc = field_of(a.ws, WS_G, HH);
-        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w11), 0, 3 * HH * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t g_rsrc = field_of(a.ws, IS_NERF ? WS_G : siren::WS_CG, HH);
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wout), 0, 3 * HH * 4, 0x00020000);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -769,18 +862,19 @@ __global__ __launch_bounds__(WG_THREADS, 2) void dgrad_x3i_kernel(DgradArgs a) {
     for (int c = 0; c < AHEAD; ++c) ring_issue(ring, c);
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- head: dz11, dsig; dz10 = (g > 0) * (dz11 . W11) as fragments and to the workspace (head_bwd of mlp_bwd.hip)
+    // ---- head (head_bwd of mlp_bwd.hip): gradient of the sigmoid outputs, of the density, and of the rgb hidden layer's
+    // pre-activations -- as fragments and to the workspace
     const auto put = [](float v, __amdgpu_buffer_rsrc_t rsrc, int voff) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff, 0, 0);
     };
     if (q == 0) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{dz11[0], dz11[1], dz11[2], 0.0f}), field_of(a.bw, BW_DZ11, 4),
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{dzo[0], dzo[1], dzo[2], 0.0f}), field_of(a.bw, BW_DZO, 4),
                                                row_local * 16, 0, 0);
         put(ds, field_of(a.bw, BW_DSIG, 1), row_local * 4);
     }
     u32x4 X[3][8];
     {
-        const __amdgpu_buffer_rsrc_t dz10 = field_of(a.bw, BW_DZ10, HH);
+        const __amdgpu_buffer_rsrc_t dzr = field_of(a.bw, BW_DZR, HH);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             float v[8];
@@ -789,11 +883,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void dgrad_x3i_kernel(DgradArgs a) {
                 f32x4 d;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float x = dz11[0] * wv[0][s][t][e] + dz11[1] * wv[1][s][t][e] + dz11[2] * wv[2][s][t][e];
-                    d[e] = gv[s][t][e] > 0.0f ? x : 0.0f;
+                    const float x = dzo[0] * wv[0][s][t][e] + dzo[1] * wv[1][s][t][e] + dzo[2] * wv[2][s][t][e];
+                    d[e] = IS_NERF ? (gv[s][t][e] > 0.0f ? x : 0.0f) : x * gv[s][t][e];
                     v[4 * t + e] = d[e];
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), dz10, row_local * HH * 4 + q * 16 + (32 * s + 16 * t) * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), dzr, row_local * HH * 4 + q * 16 + (32 * s + 16 * t) * 4, 0, 0);
             }
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) {
@@ -809,7 +903,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void dgrad_x3i_kernel(DgradArgs a) {
     asm volatile("" ::: "memory");
 
     f32x4 acc[NOT_MAX];
-    u32x4 XE[3][2];   // (no encoding k-steps in this chain)
+    u32x4 XE[3][2];   // (no encoding k-steps in these chains)
     const auto zero_acc = [&]() {
 #pragma unroll
         for (int ot = 0; ot < 16; ++ot) acc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -817,39 +911,52 @@ __global__ __launch_bounds__(WG_THREADS, 2) void dgrad_x3i_kernel(DgradArgs a) {
     constexpr int N_HEAD_STORES = 10, N_DZ_STORES = 16;
     const int voff_h = row_local * H * 4 + q * 16;
     unsigned none[2] = {0u, 0u};
-    // rgb_head.0, feature part: dz9 (block2.8 has no activation)
+    // Siren: the first derivative tiles of layer l, requested in front of the MFMA loop whose epilogue uses them
+    [[maybe_unused]] DerivTiles dv;
+    const auto layer_in = [&](int l) {
+        if constexpr (!IS_NERF) deriv_prefetch(dv, field_of(a.ws, siren::WS_C + (size_t)l * H, H), voff_h);
+    };
+    constexpr int N_PREFETCH = IS_NERF ? 0 : 2 * DERIV_AHEAD;
+    // dz(l) = d(h(l)) * activation', to the workspace and as the next layer's fragments
+    const auto layer_out = [&](int l) {
+        if constexpr (IS_NERF) {
+            // the decisions of the layer below move to the front of mk
+            unsigned mw[2] = {mk[8][0], mk[8][1]};
+#pragma unroll
+            for (int i = 8; i >= 1; --i) mk[i] = mk[i - 1];
+            to_frags_out<8, FR_MASK, FO_STORE>(acc, X, field_of(a.bw, BW_DZ + (size_t)l * H, H), voff_h, mw);
+        } else {
+            to_frags_out<8, FR_DERIV, FO_STORE>(acc, X, field_of(a.bw, BW_DZ + (size_t)l * H, H), voff_h, none,
+                                                field_of(a.ws, siren::WS_C + (size_t)l * H, H), dv);
+        }
+    };
+    // the rgb hidden layer's feature part: gradient of the features (their layer has no activation)
     zero_acc();
     mma_layer<16, 4, 0, tail(0), 0, N_HEAD_STORES>(ring, lane, acc, X, XE);
-    to_frags_out<8, FR_NONE, FO_STORE>(acc, X, field_of(a.bw, BW_DZ9, H), voff_h, none);
-    // block2.8: the feature rows on the matrix pipe, the density row as the rank-1 term dsig[sample] * w[feature]
+    to_frags_out<8, FR_NONE, FO_STORE>(acc, X, field_of(a.bw, BW_DZF, H), voff_h, none);
+    // the feature layer on the matrix pipe, the density row / branch as the rank-1 term dsig[sample] * w[feature]
 #pragma unroll
     for (int ot = 0; ot < 16; ++ot) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(bias_lds + ot * 16 + q * 4);
         acc[ot] = f32x4{ds * w[0], ds * w[1], ds * w[2], ds * w[3]};
     }
-    mma_layer<16, 8, 0, tail(1), 0, N_DZ_STORES>(ring, lane, acc, X, XE);
-    {
-        unsigned mw[2] = {mk[8][0], mk[8][1]};
-        to_frags_out<8, FR_MASK, FO_STORE>(acc, X, field_of(a.bw, BW_DZ + 8 * (size_t)H, H), voff_h, mw);
-    }
-    // block2.6 .. block1.2: dz(l-1) = (h(l-1) > 0) * (dz(l) W(l)); the decisions of the next layer move to the front of mk
+    layer_in(LAST_HIDDEN);
+    mma_layer<16, 8, 0, tail(1), 0, N_DZ_STORES + N_PREFETCH>(ring, lane, acc, X, XE);
+    layer_out(LAST_HIDDEN);
+    // the hidden layers down to the second: dz(l-1) = d(h(l-1)) * activation'
 #pragma unroll 1
-    for (int l = 8; l >= 2; --l) {
+    for (int l = LAST_HIDDEN; l >= 2; --l) {
         zero_acc();
-        mma_layer<16, 8, 0, tail(2), 0, N_DZ_STORES>(ring, lane, acc, X, XE);
-        unsigned mw[2] = {mk[7][0], mk[7][1]};
-#pragma unroll
-        for (int i = 7; i >= 1; --i) mk[i] = mk[i - 1];
-        to_frags_out<8, FR_MASK, FO_STORE>(acc, X, field_of(a.bw, BW_DZ + (size_t)(l - 1) * H, H), voff_h, mw);
+        layer_in(l - 1);
+        mma_layer<16, 8, 0, tail(2), 0, N_DZ_STORES + N_PREFETCH>(ring, lane, acc, X, XE);
+        layer_out(l - 1);
     }
-    // block1.2: dz0 ends the chain (its fragments are not needed)
+    // the second layer ends the chain with dz0 (its fragments are not needed)
     zero_acc();
-    mma_layer<16, 8, 0, 0, 0, N_DZ_STORES>(ring, lane, acc, X, XE);
-    {
-        unsigned mw[2] = {mk[7][0], mk[7][1]};
-        to_frags_out<8, FR_MASK, FO_STORE>(acc, X, field_of(a.bw, BW_DZ, H), voff_h, mw);
-    }
-    static_assert(G::NL == 10 && tail(9) == 0 && tail(8) == AHEAD, "the chain's last layer ends the stream");
+    layer_in(0);
+    mma_layer<16, 8, 0, 0, 0, N_DZ_STORES + N_PREFETCH>(ring, lane, acc, X, XE);
+    layer_out(0);
+    static_assert(G::NL == LAST_HIDDEN + 2 && tail(G::NL - 1) == 0 && tail(G::NL - 2) == AHEAD, "the chain's last layer ends the stream");
 }
 
 template <int MODEL>
@@ -888,9 +995,15 @@ int launch_fwd(const FwdArgs& a, int64_t M, void* stream, const char* who) {
 
 }  // namespace
 
-// Training forward of the bf16x3 mode (NeRF model), called by nerf_mlp_fwd_x3 with arguments it has checked: `image` is
-// what nerf_mlp_pack_bf16x3 wrote, `workspace` the activation workspace of nerf_mlp_fwd_workspace_floats.
-__attribute__((visibility("hidden"))) int nerf_x3i_fwd_train(const void* image, int64_t M, const float* points, const float* dirs,
+// Training forward of the bf16x3 mode, called by nerf_mlp_fwd_x3 with arguments it has checked: `image` is what
+// nerf_mlp_pack_bf16x3 wrote, `workspace` the activation workspace of nerf_mlp_fwd_workspace_floats.
+template <int MODEL>
+static int launch_fwd_train(const FwdArgs& a, int64_t groups, void* stream, const char* who) {
+    if (int rc = nerf_set_lds(fwd_x3i_kernel<MODEL, false, true>, LDS_BYTES)) return rc;
+    fwd_x3i_kernel<MODEL, false, true><<<(unsigned)groups, WG_THREADS, LDS_BYTES, (hipStream_t)stream>>>(a);
+    return nerf_check_launch(who);
+}
+__attribute__((visibility("hidden"))) int nerf_x3i_fwd_train(int model, const void* image, int64_t M, const float* points, const float* dirs,
                                                              const float* rays_o, const float* rays_d, const float* t, int S,
                                                              int t_per_ray, double near, double far, float* colors, float* density,
                                                              float* workspace, void* stream) {
@@ -899,26 +1012,32 @@ __attribute__((visibility("hidden"))) int nerf_x3i_fwd_train(const void* image, 
     if (groups >= (1ll << 31)) return nerf_fail(NERF_E_ARG, "%s: too many samples", who);
     FwdArgs a{static_cast<const unsigned char*>(image), M, points, dirs, rays_o, rays_d, t, S, t_per_ray,
               (float)near, (float)(far - near), colors, density, workspace, lay::padded_samples(M)};
-    if (int rc = nerf_set_lds(fwd_x3i_kernel<NERF_MODEL_NERF, false, true>, LDS_BYTES)) return rc;
-    fwd_x3i_kernel<NERF_MODEL_NERF, false, true><<<(unsigned)groups, WG_THREADS, LDS_BYTES, (hipStream_t)stream>>>(a);
-    return nerf_check_launch(who);
+    return model == NERF_MODEL_NERF ? launch_fwd_train<NERF_MODEL_NERF>(a, groups, stream, who)
+                                    : launch_fwd_train<NERF_MODEL_SIREN>(a, groups, stream, who);
 }
 
-// Data-gradient chain of the bf16x3 training mode (NeRF model), called by nerf_mlp_pack_x3 / nerf_mlp_bwd_data_x3.
-__attribute__((visibility("hidden"))) size_t nerf_x3i_dgrad_image_bytes() { return Geo<NERF_CHAIN_DGRAD>::PACKED_BYTES; }
-__attribute__((visibility("hidden"))) int nerf_x3i_dgrad_pack(const float* const* params, void* image, void* stream) {
-    return pack_image<NERF_CHAIN_DGRAD>(params, image, stream, "nerf_mlp_pack_x3");
+// Data-gradient chains of the bf16x3 training mode, called by nerf_mlp_pack_x3 / nerf_mlp_bwd_data_x3 with checked arguments.
+__attribute__((visibility("hidden"))) size_t nerf_x3i_dgrad_image_bytes(int model) {
+    return model == NERF_MODEL_NERF ? Geo<NERF_CHAIN_DGRAD>::PACKED_BYTES : Geo<SIREN_CHAIN_DGRAD>::PACKED_BYTES;
 }
-__attribute__((visibility("hidden"))) int nerf_x3i_dgrad(const void* image, const float* w11, int64_t M, const float* dcolors,
+__attribute__((visibility("hidden"))) int nerf_x3i_dgrad_pack(int model, const float* const* params, void* image, void* stream) {
+    return model == NERF_MODEL_NERF ? pack_image<NERF_CHAIN_DGRAD>(params, image, stream, "nerf_mlp_pack_x3")
+                                    : pack_image<SIREN_CHAIN_DGRAD>(params, image, stream, "nerf_mlp_pack_x3");
+}
+template <int MODEL>
+static int launch_dgrad(const DgradArgs& a, int64_t groups, void* stream, const char* who) {
+    if (int rc = nerf_set_lds(dgrad_x3i_kernel<MODEL>, LDS_BYTES)) return rc;
+    dgrad_x3i_kernel<MODEL><<<(unsigned)groups, WG_THREADS, LDS_BYTES, (hipStream_t)stream>>>(a);
+    return nerf_check_launch(who);
+}
+__attribute__((visibility("hidden"))) int nerf_x3i_dgrad(int model, const void* image, const float* wout, int64_t M, const float* dcolors,
                                                          const float* ddensity, const float* colors, const float* fwd_workspace,
                                                          float* bwd_workspace, void* stream) {
     const char* who = "nerf_mlp_bwd_data_x3";
     const int64_t groups = ceil_div64(M, WG_SAMPLES);
     if (groups >= (1ll << 31)) return nerf_fail(NERF_E_ARG, "%s: too many samples", who);
-    DgradArgs a{static_cast<const unsigned char*>(image), w11, M, lay::padded_samples(M), dcolors, ddensity, colors, fwd_workspace, bwd_workspace};
-    if (int rc = nerf_set_lds(dgrad_x3i_kernel, LDS_BYTES)) return rc;
-    dgrad_x3i_kernel<<<(unsigned)groups, WG_THREADS, LDS_BYTES, (hipStream_t)stream>>>(a);
-    return nerf_check_launch(who);
+    DgradArgs a{static_cast<const unsigned char*>(image), wout, M, lay::padded_samples(M), dcolors, ddensity, colors, fwd_workspace, bwd_workspace};
+    return model == NERF_MODEL_NERF ? launch_dgrad<NERF_MODEL_NERF>(a, groups, stream, who) : launch_dgrad<NERF_MODEL_SIREN>(a, groups, stream, who);
 }
 
 extern "C" size_t nerf_mlp_packed_bf16x3_bytes(int model) {

@@ -69,6 +69,7 @@ fi
 if [ "$ONLY" = stats ]; then
     stats hier && stats single --steps 6 --warmup 2 --sampling single && stats siren --steps 6 --warmup 2 --sampling single --model siren &&
     stats x3 --steps 6 --warmup 2 --train-precision bf16x3 && stats x3_single --steps 6 --warmup 2 --sampling single --train-precision bf16x3 &&
+    stats x3_siren --steps 6 --warmup 2 --sampling single --model siren --train-precision bf16x3 &&
     stats infer_bf16x3 --steps 6 --warmup 2 --mode infer --precision bf16x3 --rays 32768 && echo "kernel statistics collected in $OUT"
     exit $?
 fi
@@ -81,6 +82,7 @@ stats single --steps 6 --warmup 2 --sampling single &&
 stats siren --steps 6 --warmup 2 --sampling single --model siren &&
 stats x3 --steps 6 --warmup 2 --train-precision bf16x3 &&
 stats x3_single --steps 6 --warmup 2 --sampling single --train-precision bf16x3 &&
+stats x3_siren --steps 6 --warmup 2 --sampling single --model siren --train-precision bf16x3 &&
 stats infer_bf16x3 --steps 6 --warmup 2 --mode infer --precision bf16x3 --rays 32768 &&
 pmc_all &&
 modes &&

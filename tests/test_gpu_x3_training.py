@@ -189,3 +189,41 @@ def test_bf16x3_forward_fills_the_workspace_of_the_fp32_forward(M):
         decided = (words[:, word] >> bit) & 1                                      # [Mp, 256]
         h = ws3[(96 + 256 * l) * Mp:(96 + 256 * (l + 1)) * Mp].view(Mp, 256)
         assert torch.equal(decided.bool(), h > 0), f"mask of h{l}"
+
+
+@pytest.mark.parametrize("M", [1, 129, 1000])
+def test_bf16x3_siren_forward_workspace(M):
+    """Siren: x, de, h0..h7, f, g and the density pre-activation where the fp32 forward writes them, to 1e-5; the
+    derivative fields (row-major like the activations in this mode; the fp32 kernels keep theirs in accumulator order)
+    against the activations they belong to: (w0 cos)^2 / w0^2 + sin^2 = 1."""
+    from nerf import _hip
+    model, _ = make_model("siren")
+    g = torch.Generator().manual_seed(M)
+    pts = (torch.rand(M, 3, generator=g) * 2 - 1).to(DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=1).to(DEV)
+    c32, d32, ws32 = _hip.mlp_fwd(model.model_id, model.packed_weights(True), M, points=pts, dirs=dirs, train=True)
+    model.set_training_precision("bf16x3")
+    c3, d3, ws3 = _hip.mlp_fwd(model.model_id, model.packed_weights(True), M, points=pts, dirs=dirs, train=True)
+    assert rel(c3, c32) < RTOL and rel(d3, d32) < RTOL
+    Mp = -(-M // 64) * 64
+    H, HH = 256, 128
+    WS_H, WS_C = 36, 36 + 8 * H
+    WS_F = WS_C + 8 * H
+    WS_G, WS_CG, WS_SRAW = WS_F + H, WS_F + H + HH, WS_F + H + 2 * HH
+    assert ws3.numel() == ws32.numel() == Mp * (WS_SRAW + 1)
+
+    def field(ws, off, width):
+        return ws[off * Mp:(off + width) * Mp].view(Mp, width)
+
+    same = [("x", 0, 4), ("de", 4, 32)] + [(f"h{l}", WS_H + H * l, H) for l in range(8)] + [("f", WS_F, H), ("g", WS_G, HH), ("sraw", WS_SRAW, 1)]
+    for name, off, width in same:
+        a, b = field(ws3, off, width), field(ws32, off, width)
+        assert rel(a[:M], b[:M]) < RTOL, name
+        assert float((a[:M] - b[:M]).abs().max()) <= 2e-5 * max(float(b[:M].abs().max()), 1.0), name
+        assert torch.isfinite(a).all(), name
+    for l in range(8):
+        w0 = 30.0 if l == 0 else 1.0
+        h, c = field(ws3, WS_H + H * l, H).double(), field(ws3, WS_C + H * l, H).double()
+        assert float(((c / w0) ** 2 + h ** 2 - 1).abs().max()) < 1e-6, f"derivative of h{l}"
+    gg, cg = field(ws3, WS_G, HH).double(), field(ws3, WS_CG, HH).double()
+    assert float((cg ** 2 + gg ** 2 - 1).abs().max()) < 1e-6
