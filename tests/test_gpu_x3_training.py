@@ -268,3 +268,31 @@ def test_bf16x3_training_psnr_curve_matches_the_fp32_kernels():
           f"{win(c3, steps - 20):.2f} dB (bf16x3); gaps " + " ".join(f"{x:.3f}" for x in gaps) + f" dB; first 10 steps {early:.4f} dB")
     assert win(c3, steps - 20) > mse_to_psnr(c3[0]) + 6.0
     assert early < 0.01 and max(gaps) < 0.15, (early, gaps)
+
+
+@pytest.mark.parametrize("tag", ["nerf", "siren"])
+@pytest.mark.parametrize("per_ray", [False, True])
+def test_bf16x3_training_forward_in_ray_mode(tag, per_ray):
+    """Positions generated in the kernel (rays_o + t * rays_d, normalised), shared or per-ray depths, a sample count that is
+    no multiple of the 16-sample tiles or the 128-sample workgroups: outputs and the first / last hidden activations
+    against the fp32 forward on the same rays."""
+    from nerf import _hip
+    model, _ = make_model(tag)
+    R, S = 7, 50
+    o, d = rays(R, 77)
+    g = torch.Generator().manual_seed(78)
+    t = torch.sort(2.0 + 4.0 * torch.rand((R, S) if per_ray else (S,), generator=g), dim=-1)[0]
+    o, d, t = o.to(DEV), d.to(DEV), t.to(DEV).contiguous()
+    M = R * S
+    kw = dict(rays_o=o, rays_d=d, t=t, S=S, near=2.0, far=6.0, train=True)
+    c32, d32, ws32 = _hip.mlp_fwd(model.model_id, model.packed_weights(True), M, **kw)
+    model.set_training_precision("bf16x3")
+    c3, d3, ws3 = _hip.mlp_fwd(model.model_id, model.packed_weights(True), M, **kw)
+    assert rel(c3, c32) < RTOL and rel(d3, d32) < RTOL
+    Mp = -(-M // 64) * 64
+    h0 = 96 if tag == "nerf" else 36
+    last = 8 if tag == "nerf" else 7
+    for l in (0, last):
+        a = ws3[(h0 + 256 * l) * Mp:(h0 + 256 * (l + 1)) * Mp].view(Mp, 256)[:M]
+        b = ws32[(h0 + 256 * l) * Mp:(h0 + 256 * (l + 1)) * Mp].view(Mp, 256)[:M]
+        assert rel(a, b) < RTOL, f"h{l}"
