@@ -165,6 +165,8 @@ def test_device_rays_epoch_semantics(tmp_path):
     ("siren", "torch", "", []),
     ("nerf", "fused", "num_fine_samples = 16", ["--precision", "bf16"]),   # coarse + fine pair, bf16 inference
     ("nerf", "fused", "num_fine_samples = 16", ["--precision", "bf16x3"]),  # the same through the three-term kernels
+    ("siren", "fused", "train_precision = bf16x3", ["--precision", "bf16x3"]),   # the shipped model type, trained in the bf16x3 mode
+    ("nerf", "fused", "num_fine_samples = 16\ntrain_precision = bf16x3", []),    # coarse + fine pair trained in the bf16x3 mode
 ])
 def test_train_resume_eval_end_to_end(tmp_path, capsys, model_type, optimizer, extra, eval_args):
     sys.path.insert(0, PKG)
@@ -188,7 +190,7 @@ def test_train_resume_eval_end_to_end(tmp_path, capsys, model_type, optimizer, e
         assert "[Iter 0000004]" in out and "[Iter 0000003]" not in out
         ev.main(["--config", cfgp, "--checkpoint", os.path.join(save, files[2]), "--output", str(tmp_path / "frames")]
                 + eval_args)
-        if extra:
+        if "num_fine_samples" in extra:
             sd = torch.load(os.path.join(save, files[2]), map_location="cpu", weights_only=True)["model_state_dict"]
             assert any(k.startswith("coarse.") for k in sd) and any(k.startswith("fine.") for k in sd)
         from PIL import Image
