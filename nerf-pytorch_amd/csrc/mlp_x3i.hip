@@ -1,4 +1,6 @@
-// Three-term ("bf16x3") inference forward on 16-sample tiles: v_mfma_f32_16x16x32_bf16, two waves per SIMD.
+// Three-term ("bf16x3") kernels on 16-sample tiles: v_mfma_f32_16x16x32_bf16, two waves per SIMD.  The inference
+// forward of both models, and -- the same kernel with workspace outputs, and the same structure run over the
+// transposed layers -- the forward and data-gradient chain of the opt-in bf16x3 training mode (entry points: mlp_x3.hip).
 //
 // Arithmetic: every fp32 operand is the exact sum of three bf16 terms, x = x0 + x1 + x2 with x0 = bf16(x),
 // x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (the subtractions are exact), and a product is formed from the six term
