@@ -28,7 +28,7 @@ pmc() {     # name, counters...   (NeRF single-pass workload; name "siren_*" pro
     local name=$1; shift
     local model=nerf
     local work="--train-precision fp32"
-    case "$name" in siren_*) model=siren;; x3_*) work="--train-precision bf16x3";; x3i_*) work="--mode infer --precision bf16x3 --rays 32768";; esac
+    case "$name" in siren_*) model=siren;; x3siren_*) model=siren; work="--train-precision bf16x3";; x3_*) work="--train-precision bf16x3";; x3i_*) work="--mode infer --precision bf16x3 --rays 32768";; esac
     rm -rf "$OUT/pmc_$name"
     timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$OUT/pmc_$name" -o p --output-format csv -- python3 bench.py --sampling single --model $model $work --steps 3 --warmup 1 --no-cpu-baseline \
         > /dev/null 2> "$OUT/pmc_$name.log" || return 1
@@ -48,10 +48,11 @@ pmc_all() {
     pmc x3_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE &&
     pmc x3_fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
     pmc x3_write WRITE_SIZE &&
+    pmc x3siren_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
     pmc x3i_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
     pmc x3i_insts SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE &&
     pmc x3i_wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE &&
-    echo '{"samples_per_dispatch": 1048576, "command": "rocprofv3 --pmc <counters> -- python3 bench.py --sampling single [--model siren] --steps 3 --warmup 1 --no-cpu-baseline", "unit": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (profiles/summarize_pmc.py means); files named *_pmc_siren_* are the Siren network, *_pmc_x3_* the opt-in bf16x3 training kernels (--train-precision bf16x3), *_pmc_x3i_* the bf16x3 inference kernel (--mode infer --precision bf16x3 --rays 32768: 8,388,608 samples per dispatch)"}' > "$OUT/${TAG}_pmc_meta.json"
+    echo '{"samples_per_dispatch": 1048576, "command": "rocprofv3 --pmc <counters> -- python3 bench.py --sampling single [--model siren] --steps 3 --warmup 1 --no-cpu-baseline", "unit": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (profiles/summarize_pmc.py means); files named *_pmc_siren_* are the Siren network, *_pmc_x3_* the opt-in bf16x3 training kernels (--train-precision bf16x3; *_pmc_x3siren_* the Siren network in that mode), *_pmc_x3i_* the bf16x3 inference kernel (--mode infer --precision bf16x3 --rays 32768: 8,388,608 samples per dispatch)"}' > "$OUT/${TAG}_pmc_meta.json"
 }
 modes() {
     : > "$OUT/${TAG}_bench_modes.jsonl"
